@@ -1,0 +1,67 @@
+"""Deterministic synthetic point clouds (SURVEY.md §8d "Synthetic inputs").
+
+numpy-only so the same seed gives the same bytes in the golden generator, the
+tests, the oracle timing leg and bench.py, on any torch version.
+
+"ScanNet-shaped": a room box with 60 % of the points snapped to six planes
+(floor / ceiling / four walls) plus a little noise, then the reference's own
+input normalisation (reference inference.py:88-91: subtract the centroid,
+divide by max |.|), rgb ~ U[0,1].  "LiDAR-shaped": 64 rings, range U[2,80] m.
+"""
+import numpy as np
+
+
+def _normalise_xyz(xyz: np.ndarray) -> np.ndarray:
+    # reference inference.py:88-91, in float64 like the reference, cast at the end
+    xyz = xyz - xyz.mean(axis=0)
+    scale = np.max(np.abs(xyz))
+    if scale > 0:
+        xyz = xyz / scale
+    return xyz
+
+
+def scannet_like_cloud(n: int, rng: np.random.Generator) -> np.ndarray:
+    """One cloud, (n, 6) float32: xyz normalised to the unit inf-ball, rgb in [0,1]."""
+    box = np.array([8.0, 6.0, 3.0])
+    xyz = rng.random((n, 3)) * box
+    snap = rng.random(n) < 0.6
+    plane = rng.integers(0, 6, size=n)
+    axis = plane // 2
+    side = (plane % 2).astype(np.float64)
+    rows = np.nonzero(snap)[0]
+    xyz[rows, axis[rows]] = side[rows] * box[axis[rows]]
+    xyz += rng.normal(0.0, 0.01, size=(n, 3))
+    xyz = _normalise_xyz(xyz)
+    rgb = rng.random((n, 3))
+    return np.concatenate([xyz, rgb], axis=1).astype(np.float32)
+
+
+def lidar_like_cloud(n: int, rng: np.random.Generator) -> np.ndarray:
+    """One cloud, (n, 6) float32, 64-ring spinning-LiDAR geometry."""
+    ring = rng.integers(0, 64, size=n)
+    elev = np.deg2rad(-24.8 + ring * (26.8 / 63.0))
+    azim = rng.random(n) * 2.0 * np.pi
+    rng_m = 2.0 + rng.random(n) * 78.0
+    xyz = np.stack([rng_m * np.cos(elev) * np.cos(azim),
+                    rng_m * np.cos(elev) * np.sin(azim),
+                    rng_m * np.sin(elev)], axis=1)
+    xyz = _normalise_xyz(xyz)
+    rgb = rng.random((n, 3))
+    return np.concatenate([xyz, rgb], axis=1).astype(np.float32)
+
+
+def make_batch(b: int, n: int, seed: int, kind: str = "scannet") -> np.ndarray:
+    """(b, n, 6) float32 contiguous batch; cloud i uses stream (seed, i)."""
+    gen = scannet_like_cloud if kind == "scannet" else lidar_like_cloud
+    out = np.empty((b, n, 6), dtype=np.float32)
+    for i in range(b):
+        out[i] = gen(n, np.random.default_rng([seed, i]))
+    return out
+
+
+def make_labels(b: int, n: int, seed: int, num_instances: int = 33) -> np.ndarray:
+    """(b, n) int64 instance labels in [0, num_instances) (0 = background);
+    33.2 instances/scene on average in the reference's dataset
+    (reference analysis_results/dataset_statistics.txt:7)."""
+    rng = np.random.default_rng([seed, 7919])
+    return rng.integers(0, num_instances, size=(b, n)).astype(np.int64)
