@@ -1,0 +1,111 @@
+/*
+ * p2n.h -- C ABI of the MI355X-native Point2Net hot path (libp2n_hip.so).
+ *
+ * The reference (ahmad-kad/PointCloudSegmentation) has NO native/FFI layer: its
+ * boundary for this path is the Python import `from src.models.point2net import
+ * Point2Net` (reference train.py:16, inference.py:12) and `from
+ * src.models.losses import InstanceSegLoss` (reference train.py:19).  The entry
+ * points below are what a ctypes binding inside those modules calls; each one
+ * cites the reference lines whose arithmetic it replaces.  INTEGRATION.md shows
+ * the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor data_ptr)
+ *     unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - nothing here allocates: outputs and workspaces come from the caller;
+ *   - all calls are asynchronous on `stream`; return value 0 = launched OK,
+ *     otherwise one of P2N_E*; p2n_last_error() gives a thread-local message;
+ *   - float = IEEE binary32, indices = int32_t, layouts are contiguous
+ *     row-major in the order written.
+ */
+#ifndef P2N_H
+#define P2N_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2N_OK 0
+#define P2N_EINVAL 1      /* bad shape / argument */
+#define P2N_EWORKSPACE 2  /* workspace too small */
+#define P2N_EHIP 3        /* HIP runtime error (message has hipGetErrorString) */
+
+int p2n_version(void);
+const char *p2n_last_error(void);
+
+/* ---- parameters ---------------------------------------------------------
+ * Raw parameter buffer = the reference model's state_dict flattened in layer
+ * order (reference point2net.py:9-34, 57-65): for l = 0..8 with (Cin,Cout) =
+ * (F,64)(64,64)(64,128)(128,128)(128,256)(256,256)(512,256)(256,128)(128,E):
+ * W (Cout,Cin), bias (Cout), and for l < 8 bn.weight, bn.bias, running_mean,
+ * running_var (Cout each). */
+long p2n_param_count(int feature_dim, int embedding_dim);
+/* Size (floats) of the eval-mode packed image: weights re-ordered into MFMA
+ * fragment order, BatchNorm(eval) folded into per-channel scale/shift. */
+long p2n_packed_param_count(int feature_dim, int embedding_dim);
+/* Build the packed image from raw params.  Replaces nothing in the reference
+ * (it is the load_state_dict-time preparation of reference inference.py:63-74). */
+int p2n_pack_eval_params(const float *raw, int feature_dim, int embedding_dim, float *packed, void *stream);
+
+/* ---- eval forward --------------------------------------------------------
+ * Point2Net.forward in eval mode (reference point2net.py:67-87; encoder
+ * :36-48): x (B,N,F) -> emb (B,N,E).  Optional outputs (NULL to skip):
+ * global_f (B,256) = reference point2net.py:46; f1 (B,64,N), f2 (B,128,N),
+ * f3 (B,256,N) = the encoder's returned features (reference point2net.py:41-43).
+ * emb may be NULL too (encoder-only call: the head kernel is skipped).
+ * Supported: 1 <= F <= 8, 1 <= E <= 256, B,N >= 1 (B*N = 0 is a no-op). */
+size_t p2n_forward_eval_workspace_bytes(int B, int N, int feature_dim, int embedding_dim);
+int p2n_forward_eval(const float *x, int B, int N, int feature_dim, int embedding_dim,
+                     const float *packed, float *emb, float *global_f,
+                     float *f1, float *f2, float *f3,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- point-set operators (named by BASELINE.json north_star; the reference has
+ * none of them -- SURVEY.md section 0 -- so oracle/p2n_oracle.c is their spec:
+ * fp32 squared distance ((dx*dx+dy*dy)+dz*dz) without fma, lowest index wins
+ * ties). ----------------------------------------------------------------- */
+
+/* Farthest-point sampling: xyz (B,N,3) -> idx (B,M); first sample = start_idx. */
+size_t p2n_fps_workspace_bytes(int B, int N, int M);
+int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx,
+            void *workspace, size_t workspace_bytes, void *stream);
+
+/* Ball query: xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample): first nsample
+ * indices (ascending) with d2 < radius^2, padded with the first hit (0 if none). */
+int p2n_ball_query(const float *xyz, const float *new_xyz, int B, int N, int M,
+                   float radius, int nsample, int32_t *idx, void *stream);
+
+/* Brute-force kNN: query (B,M,3), ref (B,N,3) -> idx (B,M,k), d2 (B,M,k) (d2 may
+ * be NULL): the k smallest (d2,index) pairs, ascending.  Exact-arithmetic form
+ * of reference losses.py:475-479 (cdist + topk(k+1) whose column 0 the caller
+ * drops).  1 <= k <= 64, k <= N. */
+int p2n_knn(const float *query, const float *ref, int B, int M, int N, int k,
+            int32_t *idx, float *d2, void *stream);
+
+/* Grouping gather: feat (B,C,N), idx (B,M,ns) -> out (B,C,M,ns). */
+int p2n_group_gather(const float *feat, const int32_t *idx, int B, int C, int N, int M, int ns,
+                     float *out, void *stream);
+/* Its adjoint: grad_out (B,C,M,ns) scattered-added into grad_feat (B,C,N)
+ * (grad_feat is zeroed by the call). */
+int p2n_group_gather_bwd(const float *grad_out, const int32_t *idx, int B, int C, int N, int M, int ns,
+                         float *grad_feat, void *stream);
+
+/* Three nearest neighbours + fused inverse-distance weights:
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3), idx (B,n,3), weight (B,n,3)
+ * (weight may be NULL); w_j = (1/(d2_j+1e-8)) / sum_j. */
+int p2n_three_nn(const float *unknown, const float *known, int B, int n, int m,
+                 float *dist2, int32_t *idx, float *weight, void *stream);
+/* Feature propagation: feat (B,C,m), idx/weight (B,n,3) -> out (B,C,n). */
+int p2n_three_interpolate(const float *feat, const int32_t *idx, const float *weight,
+                          int B, int C, int m, int n, float *out, void *stream);
+int p2n_three_interpolate_bwd(const float *grad_out, const int32_t *idx, const float *weight,
+                              int B, int C, int m, int n, float *grad_feat, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2N_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of libp2n_hip.so (include/p2n.h).
+
+The library is built in-tree by pointcloudsegmentation_amd/csrc/Makefile
+(`__graft_entry__.build()`); there is no fallback: a missing or unloadable
+library raises, so a GPU path can never silently run on something else.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp2n_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+c_f = ctypes.c_void_p      # device float*
+c_i = ctypes.c_void_p      # device int32*
+c_vp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_float = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/p2n.h one to one
+SIGNATURES = {
+    "p2n_version": (c_int, []),
+    "p2n_last_error": (ctypes.c_char_p, []),
+    "p2n_param_count": (ctypes.c_long, [c_int, c_int]),
+    "p2n_packed_param_count": (ctypes.c_long, [c_int, c_int]),
+    "p2n_pack_eval_params": (c_int, [c_f, c_int, c_int, c_f, c_vp]),
+    "p2n_forward_eval_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "p2n_forward_eval": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    "p2n_fps_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "p2n_fps": (c_int, [c_f, c_int, c_int, c_int, c_int, c_i, c_vp, c_sz, c_vp]),
+    "p2n_ball_query": (c_int, [c_f, c_f, c_int, c_int, c_int, c_float, c_int, c_i, c_vp]),
+    "p2n_knn": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_i, c_f, c_vp]),
+    "p2n_group_gather": (c_int, [c_f, c_i, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]),
+    "p2n_group_gather_bwd": (c_int, [c_f, c_i, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]),
+    "p2n_three_nn": (c_int, [c_f, c_f, c_int, c_int, c_int, c_f, c_i, c_f, c_vp]),
+    "p2n_three_interpolate": (c_int, [c_f, c_i, c_f, c_int, c_int, c_int, c_int, c_f, c_vp]),
+    "p2n_three_interpolate_bwd": (c_int, [c_f, c_i, c_f, c_int, c_int, c_int, c_int, c_f, c_vp]),
+}
+
+
+class P2nError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libp2n_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise P2nError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no fallback path for GPU tensors)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)   # AttributeError = header/library mismatch: let it propagate
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().p2n_last_error().decode(errors="replace")
+        if rc == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise P2nError(f"{what}: rc={rc}: {msg}")

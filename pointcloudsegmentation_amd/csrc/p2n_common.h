@@ -1,0 +1,90 @@
+// Shared host/device definitions of libp2n_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/p2n.h"
+
+#define P2N_NLAYER 9
+#define P2N_WAVE 64
+#define P2N_PTS_PER_WAVE 32          // one 32-column MFMA block of points per wave
+#define P2N_WAVES_PER_WG 4
+#define P2N_PTS_PER_WG (P2N_PTS_PER_WAVE * P2N_WAVES_PER_WG)
+#define P2N_RING 8                   // weight fragments kept in flight per wave
+#define P2N_FRAG_FLOATS 256          // one fragment = 64 lanes x 4 floats = 1 KiB
+#define P2N_TAB_MAX 1792             // encoder scale/shift tables: 2*(64+64+128+128+256+256)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Packed eval-parameter image.  All offsets in floats from the image base.
+struct P2nLayout {
+    int F, E;
+    int cin[P2N_NLAYER], cout[P2N_NLAYER];
+    int kpad[P2N_NLAYER];   // reduction length the kernels run (multiple of 8; layer 6: f3 half only)
+    int cpad[P2N_NLAYER];   // output channels rounded up to 32
+    long raw_w[P2N_NLAYER], raw_b[P2N_NLAYER], raw_g[P2N_NLAYER], raw_beta[P2N_NLAYER],
+        raw_mean[P2N_NLAYER], raw_var[P2N_NLAYER];
+    long raw_total;
+    long enc_stream;        // layers 0..5, fragment order, then P2N_RING zero fragments
+    long enc_frags;
+    long head_stream;       // (layer 6 tile, layer 7 k-slice) x 8, then layer 8, then zero fragments
+    long head_frags;
+    long scale[P2N_NLAYER], shift[P2N_NLAYER];
+    long w6g;               // (256,256) row-major: the global-feature half of layer 6
+    long total;
+};
+
+static inline P2nLayout p2n_make_layout(int F, int E) {
+    P2nLayout L;
+    const int ci[P2N_NLAYER] = {F, 64, 64, 128, 128, 256, 512, 256, 128};
+    const int co[P2N_NLAYER] = {64, 64, 128, 128, 256, 256, 256, 128, E};
+    L.F = F; L.E = E;
+    long r = 0;
+    for (int l = 0; l < P2N_NLAYER; ++l) {
+        L.cin[l] = ci[l]; L.cout[l] = co[l];
+        L.kpad[l] = (l == 0) ? 8 : (l == 6 ? 256 : ci[l]);
+        L.cpad[l] = (co[l] + 31) / 32 * 32;
+        L.raw_w[l] = r; r += (long)ci[l] * co[l];
+        L.raw_b[l] = r; r += co[l];
+        if (l < 8) {
+            L.raw_g[l] = r; r += co[l];
+            L.raw_beta[l] = r; r += co[l];
+            L.raw_mean[l] = r; r += co[l];
+            L.raw_var[l] = r; r += co[l];
+        } else {
+            L.raw_g[l] = L.raw_beta[l] = L.raw_mean[l] = L.raw_var[l] = -1;
+        }
+    }
+    L.raw_total = r;
+    long o = 0;
+    L.enc_stream = o;
+    L.enc_frags = 0;
+    for (int l = 0; l < 6; ++l) L.enc_frags += (long)(L.cpad[l] / 32) * (L.kpad[l] / 8);
+    o += (L.enc_frags + P2N_RING) * P2N_FRAG_FLOATS;
+    L.head_stream = o;
+    L.head_frags = 8L * (32 + 16) + (long)(L.cpad[8] / 32) * 16;
+    o += (L.head_frags + P2N_RING) * P2N_FRAG_FLOATS;
+    for (int l = 0; l < P2N_NLAYER; ++l) { L.scale[l] = o; o += L.cpad[l]; L.shift[l] = o; o += L.cpad[l]; }
+    L.w6g = o; o += 256L * 256;
+    L.total = o;
+    return L;
+}
+
+// ---- error plumbing (p2n_api.hip) ----
+void p2n_set_error(const char *fmt, ...);
+#define P2N_CHECK_HIP(expr)                                                          \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            p2n_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return P2N_EHIP;                                                         \
+        }                                                                            \
+    } while (0)
+#define P2N_REQUIRE(cond, ...)                  \
+    do {                                        \
+        if (!(cond)) {                          \
+            p2n_set_error(__VA_ARGS__);         \
+            return P2N_EINVAL;                  \
+        }                                       \
+    } while (0)

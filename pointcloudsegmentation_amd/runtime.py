@@ -1,0 +1,81 @@
+"""Thin host runtime over the C ABI: streams, workspaces, pointer plumbing.
+
+PyTorch is used for device memory and streams only; every kernel on a GPU tensor
+goes through libp2n_hip.so (see _lib.py) and there is no fallback.
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Per (device, stream) scratch buffer, grown on demand and reused: kernels on one
+    stream run in order, so consecutive calls can share it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_handle(device))
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def pack_eval_params(raw: torch.Tensor, feature_dim: int, embedding_dim: int) -> torch.Tensor:
+    """raw flat float32 params on the GPU -> packed eval image (see include/p2n.h)."""
+    L = _lib.lib()
+    n = L.p2n_packed_param_count(feature_dim, embedding_dim)
+    if n < 0:
+        raise ValueError(f"unsupported feature_dim={feature_dim} / embedding_dim={embedding_dim} "
+                         "(HIP path supports 1..8 / 1..256)")
+    if raw.numel() != L.p2n_param_count(feature_dim, embedding_dim):
+        raise ValueError("raw parameter buffer has the wrong size")
+    raw = require_cuda_f32(raw, "raw")
+    packed = torch.empty(n, dtype=torch.float32, device=raw.device)
+    with torch.cuda.device(raw.device):
+        _lib.check(L.p2n_pack_eval_params(raw.data_ptr(), feature_dim, embedding_dim, packed.data_ptr(),
+                                          stream_handle(raw.device)), "p2n_pack_eval_params")
+    return packed
+
+
+def forward_eval(x: torch.Tensor, packed: torch.Tensor, embedding_dim: int, want_global: bool = False,
+                 want_features: bool = False, want_embedding: bool = True):
+    """x (B,N,F) -> emb (B,N,E) [, global_f (B,256)] [, f1, f2, f3]."""
+    L = _lib.lib()
+    x = require_cuda_f32(x, "x")
+    if x.dim() != 3:
+        raise ValueError(f"x must be (B,N,C), got {tuple(x.shape)}")
+    B, N, F = x.shape
+    E = embedding_dim
+    dev = x.device
+    emb = torch.empty((B, N, E), dtype=torch.float32, device=dev) if want_embedding else None
+    g = torch.empty((B, 256), dtype=torch.float32, device=dev) if (want_global or want_features) else None
+    f1 = torch.empty((B, 64, N), dtype=torch.float32, device=dev) if want_features else None
+    f2 = torch.empty((B, 128, N), dtype=torch.float32, device=dev) if want_features else None
+    f3 = torch.empty((B, 256, N), dtype=torch.float32, device=dev) if want_features else None
+    if B * N > 0:
+        nbytes = L.p2n_forward_eval_workspace_bytes(B, N, F, E)
+        ws = workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.p2n_forward_eval(x.data_ptr(), B, N, F, E, packed.data_ptr(), ptr(emb), ptr(g),
+                                          ptr(f1), ptr(f2), ptr(f3), ws.data_ptr(), ws.numel(),
+                                          stream_handle(dev)), "p2n_forward_eval")
+    return emb, g, f1, f2, f3
