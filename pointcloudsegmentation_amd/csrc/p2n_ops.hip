@@ -1,0 +1,534 @@
+// Point-set operators for gfx950 (MI355X): farthest-point sampling, ball query,
+// brute-force kNN / three-NN, grouping gather, inverse-distance interpolation.
+//
+// The reference has none of these except the brute-force kNN
+// inside its smoothness loss (reference losses.py:475-479); their specification is
+// oracle/p2n_oracle.c: fp32 squared distance ((dx*dx + dy*dy) + dz*dz) with separate
+// multiply and add, lowest index wins ties.  All kernels below evaluate exactly that
+// expression (explicit __fmul_rn/__fadd_rn), so indices are bit-exact by construction.
+#include "p2n_common.h"
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+typedef unsigned long long u64;
+
+// =========================================================================== FPS
+// A cluster of G workgroups (1024 threads each) owns one cloud; every thread keeps
+// PPT points (x, y, z, running min distance) in REGISTERS for the whole kernel, so
+// an iteration touches no memory except the winner exchange:
+//   thread argmax -> DPP/shuffle wave argmax -> LDS -> workgroup argmax  (1 barrier)
+//   G > 1: lane 0 publishes the workgroup's 64-bit key with one agent-scope atomic
+//   store into slot[it][g]; wave 0 polls the G slots of this iteration (zero = not
+//   yet written; slots are per iteration, so no tags or resets), reduces them and
+//   reads the winner's coordinates from xyz (immutable input).          (+1 barrier)
+// key = (bits(min_dist) << 32) | (0xFFFFFFFF - index): max key = farthest point,
+// lowest index on ties.  min_dist >= 0 so its bit pattern orders as an unsigned.
+#define FPS_THREADS 1024
+#define FPS_WAVES (FPS_THREADS / 64)
+#define FPS_SPIN_LIMIT (1 << 22)
+#define FPS_MAX_PPT 20   // 24 points per thread spill past the 128-VGPR budget of a 1024-thread workgroup
+
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+struct FpsArgs {
+    const float *xyz;   // (B,N,3)
+    int32_t *idx;       // (B,M)
+    u64 *slots;         // [clouds of this launch][M][G], zeroed per launch (G > 1 only)
+    int *status;        // 0 ok, 1 = exchange timed out
+    int N, M, G, chunk, start_idx, b0;
+};
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_THREADS) void p2n_fps_kernel(FpsArgs A) {
+    __shared__ u64 wkey[2][FPS_WAVES];
+    __shared__ float wxyz[2][FPS_WAVES][4];
+    __shared__ float bc[2][4];   // broadcast of the iteration's winner (G > 1)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = A.b0 + blockIdx.x / A.G, g = blockIdx.x % A.G;
+    const float *P = A.xyz + (long)b * A.N * 3;
+    const int base = g * A.chunk;
+    int nloc = A.N - base;
+    if (nloc > A.chunk) nloc = A.chunk;
+    if (nloc < 0) nloc = 0;
+
+    // Slot s of thread t is point base + t + 1024*s.  Slots past the chunk hold the origin
+    // with running minimum 0: min(0, d) stays 0, and their (virtual) index is larger than
+    // every real index of the cloud, so they lose every tie against a real point and need
+    // no special casing in the loop below.
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int i = t + FPS_THREADS * s;
+        const bool ok = i < nloc;
+        px[s] = ok ? P[(long)(base + i) * 3 + 0] : 0.f;
+        py[s] = ok ? P[(long)(base + i) * 3 + 1] : 0.f;
+        pz[s] = ok ? P[(long)(base + i) * 3 + 2] : 0.f;
+        md[s] = ok ? __int_as_float(0x7f800000) : 0.f;
+    }
+    int cur = A.start_idx;
+    float cx = P[(long)cur * 3 + 0], cy = P[(long)cur * 3 + 1], cz = P[(long)cur * 3 + 2];
+    bool dead = false;
+    const unsigned inv0 = 0xFFFFFFFFu - (unsigned)(base + t);
+
+    for (int it = 0; it < A.M; ++it) {
+        if (g == 0 && t == 0) A.idx[(long)b * A.M + it] = cur;
+        if (it + 1 == A.M) break;
+        // ---- update running minima, thread-local argmax (first maximum wins: indices ascend with s)
+        unsigned invb = inv0;
+        asm volatile("" : "+v"(invb));   // keep the per-slot index arithmetic inside the iteration (registers)
+        float best, bx = px[0], by = py[0], bz = pz[0];
+        unsigned binv = invb;
+        {
+            const float d = sqdist3(px[0], py[0], pz[0], cx, cy, cz);
+            best = md[0] = fminf(md[0], d);
+        }
+#pragma unroll
+        for (int s = 1; s < PPT; ++s) {
+            const float d = sqdist3(px[s], py[s], pz[s], cx, cy, cz);
+            const float m = fminf(md[s], d);
+            md[s] = m;
+            const bool take = m > best;
+            best = take ? m : best;
+            binv = take ? invb - (unsigned)(FPS_THREADS * s) : binv;
+            bx = take ? px[s] : bx;
+            by = take ? py[s] : by;
+            bz = take ? pz[s] : bz;
+        }
+        const u64 key = ((u64)__float_as_uint(best) << 32) | binv;
+        const u64 wmax = wave_max_u64(key);
+        const int buf = it & 1;
+        if (key == wmax) {   // keys are unique within a cloud: exactly one lane
+            wkey[buf][wave] = wmax;
+            wxyz[buf][wave][0] = bx; wxyz[buf][wave][1] = by; wxyz[buf][wave][2] = bz;
+        }
+        __syncthreads();
+        // workgroup argmax: 16 wave keys, one per lane, reduced inside every wave
+        const u64 mine = wkey[buf][lane & (FPS_WAVES - 1)];
+        u64 k = mine;
+#pragma unroll
+        for (int o = 1; o < FPS_WAVES; o <<= 1) {
+            const u64 o2 = __shfl_xor(k, o);
+            k = o2 > k ? o2 : k;
+        }
+        const int kw = __builtin_ctzll(__ballot(mine == k)) & (FPS_WAVES - 1);
+        if (A.G == 1) {
+            cur = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));
+            cx = wxyz[buf][kw][0]; cy = wxyz[buf][kw][1]; cz = wxyz[buf][kw][2];
+        } else {
+            if (wave == 0) {
+                u64 *slot = A.slots + ((long)(b - A.b0) * A.M + it) * A.G;
+                if (lane == 0) __hip_atomic_store(slot + g, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u64 v = 0;
+                int spins = 0;
+                bool ok;
+                for (;;) {
+                    // lanes >= G read nothing and count as ready; G <= 64
+                    v = (lane < A.G) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull;
+                    ok = __all(v != 0ull);
+                    if (ok || ++spins > FPS_SPIN_LIMIT) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane >= A.G) v = 0;
+                const u64 win = wave_max_u64(v);
+                int widx = (int)(0xFFFFFFFFu - (unsigned)(win & 0xFFFFFFFFu));
+                if (!ok || widx < 0 || widx >= A.N) widx = -1;
+                if (lane < 3) bc[buf][lane] = widx >= 0 ? P[(long)widx * 3 + lane] : 0.f;
+                if (lane == 3) bc[buf][3] = __int_as_float(widx);
+            }
+            __syncthreads();
+            cur = __float_as_int(bc[buf][3]);
+            cx = bc[buf][0]; cy = bc[buf][1]; cz = bc[buf][2];
+            if (cur < 0) { dead = true; break; }   // uniform: every thread reads the same word
+        }
+    }
+    if (dead && t == 0) atomicExch(A.status, 1);
+}
+
+static int fps_pick_g(int B, int N) {
+    // one workgroup holds up to FPS_MAX_PPT points per thread; prefer ~8 per thread when the
+    // chip has spare CUs, but all B*G workgroups must be co-resident (<= 256)
+    const int cap = FPS_THREADS * FPS_MAX_PPT;
+    int gmin = (N + cap - 1) / cap;
+    int gwant = (N + FPS_THREADS * 8 - 1) / (FPS_THREADS * 8);
+    int gmax = 256 / (B < 256 ? B : 256);
+    if (gmax < 1) gmax = 1;
+    if (gmax > 64) gmax = 64;
+    int G = gwant;
+    if (G > gmax) G = gmax;
+    if (G < gmin) G = gmin;
+    if (N <= cap && G > 1 && N <= FPS_THREADS * 12) G = 1;   // small clouds: the exchange costs more than it saves
+    return G;
+}
+
+extern "C" size_t p2n_fps_workspace_bytes(int B, int N, int M) {
+    if (B < 1 || N < 1 || M < 1) return 16;
+    const int G = fps_pick_g(1, N);   // the largest G any sub-batch can use
+    return 16 + (G > 1 ? sizeof(u64) * (size_t)B * M * 64 : 0);
+}
+
+template <int PPT>
+static void fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
+    hipLaunchKernelGGL(p2n_fps_kernel<PPT>, dim3(nb * a.G), dim3(FPS_THREADS), 0, s, a);
+}
+
+extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, void *workspace,
+                       size_t workspace_bytes, void *stream_) {
+    P2N_REQUIRE(B >= 0 && N >= 1 && M >= 0, "p2n_fps: bad shape B=%d N=%d M=%d", B, N, M);
+    P2N_REQUIRE(start_idx >= 0 && start_idx < N, "p2n_fps: start_idx %d outside [0,%d)", start_idx, N);
+    if (B == 0 || M == 0) return P2N_OK;
+    P2N_REQUIRE(xyz && idx, "p2n_fps: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t need = p2n_fps_workspace_bytes(B, N, M);
+    if (!workspace || workspace_bytes < need) {
+        p2n_set_error("p2n_fps: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    const int cap = FPS_THREADS * FPS_MAX_PPT;
+    // sub-batches so that every launch's workgroups are co-resident (<= 256)
+    int done = 0;
+    P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));
+    while (done < B) {
+        int nb = B - done;
+        if (nb > 256) nb = 256;
+        int G = fps_pick_g(nb, N);
+        if ((long)G * cap < N) {   // cloud too large to be resident with this many clouds in flight
+            nb = 256 / ((N + cap - 1) / cap);
+            P2N_REQUIRE(nb >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 256 * cap);
+            if (nb > B - done) nb = B - done;
+            G = fps_pick_g(nb, N);
+        }
+        P2N_REQUIRE(G <= 64 && (long)G * cap >= N, "p2n_fps: N=%d needs more than 64 workgroups per cloud", N);
+        FpsArgs a;
+        a.xyz = xyz; a.idx = idx; a.status = (int *)workspace;
+        a.slots = (u64 *)((char *)workspace + 16);
+        a.N = N; a.M = M; a.G = G; a.chunk = (N + G - 1) / G; a.start_idx = start_idx; a.b0 = done;
+        if (G > 1)   // launches run in stream order, so they can share the slot region
+            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 16, 0, sizeof(u64) * (size_t)nb * M * G, stream));
+        const int ppt = (a.chunk + FPS_THREADS - 1) / FPS_THREADS;
+        if (ppt <= 1) fps_launch<1>(a, nb, stream);
+        else if (ppt <= 2) fps_launch<2>(a, nb, stream);
+        else if (ppt <= 4) fps_launch<4>(a, nb, stream);
+        else if (ppt <= 8) fps_launch<8>(a, nb, stream);
+        else if (ppt <= 12) fps_launch<12>(a, nb, stream);
+        else if (ppt <= 16) fps_launch<16>(a, nb, stream);
+        else fps_launch<20>(a, nb, stream);
+        P2N_CHECK_HIP(hipGetLastError());
+        done += nb;
+    }
+    return P2N_OK;
+}
+
+// =========================================================================== ball query
+// One thread per query, the cloud streamed through LDS as SoA tiles (coalesced
+// loads, broadcast ds_read_b128 of four x / y / z at a time).
+#define BQ_THREADS 256
+#define BQ_TILE 2048
+
+__global__ __launch_bounds__(BQ_THREADS) void p2n_ball_query_kernel(const float *__restrict__ xyz,
+                                                                   const float *__restrict__ new_xyz, int N, int M,
+                                                                   float r2, int ns, int32_t *__restrict__ idx) {
+    __shared__ __attribute__((aligned(16))) float sx[BQ_TILE], sy[BQ_TILE], sz[BQ_TILE];
+    const int b = blockIdx.y, m = blockIdx.x * BQ_THREADS + threadIdx.x;
+    const bool active = m < M;
+    const float *P = xyz + (long)b * N * 3;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) {
+        const float *q = new_xyz + ((long)b * M + m) * 3;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
+    int32_t *o = idx + ((long)b * M + (active ? m : 0)) * ns;
+    int cnt = active ? 0 : ns, first = 0;
+    for (int t0 = 0; t0 < N; t0 += BQ_TILE) {
+        const int tn = min(BQ_TILE, N - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += BQ_THREADS) {
+            sx[i] = P[(long)(t0 + i) * 3 + 0];
+            sy[i] = P[(long)(t0 + i) * 3 + 1];
+            sz[i] = P[(long)(t0 + i) * 3 + 2];
+        }
+        __syncthreads();
+        if (__syncthreads_and(cnt >= ns)) break;
+        if (cnt < ns) {
+            for (int i = 0; i < tn && cnt < ns; i += 4) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(&sx[i]);
+                const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&sy[i]);
+                const f32x4 z4 = *reinterpret_cast<const f32x4 *>(&sz[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (i + j < tn && cnt < ns && sqdist3(x4[j], y4[j], z4[j], qx, qy, qz) < r2) {
+                        if (cnt == 0) first = t0 + i + j;
+                        o[cnt++] = t0 + i + j;
+                    }
+                }
+            }
+        }
+    }
+    if (active)
+        for (int s = cnt; s < ns; ++s) o[s] = first;
+}
+
+extern "C" int p2n_ball_query(const float *xyz, const float *new_xyz, int B, int N, int M, float radius, int nsample,
+                              int32_t *idx, void *stream) {
+    P2N_REQUIRE(B >= 0 && N >= 1 && M >= 0 && nsample >= 1, "p2n_ball_query: bad shape B=%d N=%d M=%d nsample=%d", B,
+                N, M, nsample);
+    if (B == 0 || M == 0) return P2N_OK;
+    P2N_REQUIRE(xyz && new_xyz && idx, "p2n_ball_query: null pointer");
+    P2N_REQUIRE(B <= 65535, "p2n_ball_query: B > 65535");
+    hipLaunchKernelGGL(p2n_ball_query_kernel, dim3((M + BQ_THREADS - 1) / BQ_THREADS, B), dim3(BQ_THREADS), 0,
+                       (hipStream_t)stream, xyz, new_xyz, N, M, radius * radius, nsample, idx);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+// =========================================================================== kNN
+// One WAVE per query.  The wave's current k best (d2, index) pairs live one per lane,
+// sorted by lane number, in two VGPRs: no LDS lists, no divergence.  Each step the 64
+// lanes test 64 consecutive reference points (SoA tile in LDS, conflict-free reads)
+// against the k-th best; survivors (a ballot mask, walked in index order) are inserted
+// by one DPP shift-right-by-one of the sorted list.  Candidates arrive in ascending
+// index order, so "strictly smaller distance goes in front" is the lowest-index
+// tie-break of the oracle.
+#define KNN_WAVES 8
+#define KNN_TILE 4096   // reference points per LDS tile (48 KiB)
+
+__device__ __forceinline__ float dpp_wave_shr1(float v, float fill) {
+    // lane l <- lane l-1; lane 0 <- fill
+    const float up = __shfl_up(v, 1);
+    return (threadIdx.x & 63) == 0 ? fill : up;
+}
+
+__global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__restrict__ query,
+                                                                const float *__restrict__ ref, int M, int N, int k,
+                                                                int32_t *__restrict__ idx, float *__restrict__ d2out,
+                                                                float *__restrict__ wout) {
+    __shared__ __attribute__((aligned(16))) float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const long m = (long)blockIdx.x * KNN_WAVES + wave;
+    const bool active = m < M;
+    const float *P = ref + (long)b * N * 3;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) {
+        const float *q = query + ((long)b * M + m) * 3;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
+    const float INF = __int_as_float(0x7f800000);
+    float ld = INF;   // lane l holds the l-th smallest distance seen so far
+    int li = -1;
+    float kth = INF;
+    for (int t0 = 0; t0 < N; t0 += KNN_TILE) {
+        const int tn = min(KNN_TILE, N - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += KNN_WAVES * 64) {
+            sx[i] = P[(long)(t0 + i) * 3 + 0];
+            sy[i] = P[(long)(t0 + i) * 3 + 1];
+            sz[i] = P[(long)(t0 + i) * 3 + 2];
+        }
+        __syncthreads();
+        if (!active) continue;
+        for (int i0 = 0; i0 < tn; i0 += 64) {
+            const int i = i0 + lane;
+            const float d = (i < tn) ? sqdist3(sx[i], sy[i], sz[i], qx, qy, qz) : INF;
+            unsigned long long mask = __ballot(d < kth);
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float cd = __shfl(d, src);
+                if (!(cd < kth)) continue;          // the k-th best tightened since the ballot
+                const int ci = t0 + i0 + src;
+                const bool gt = ld > cd;            // this lane's entry moves one rank down
+                const float pd = dpp_wave_shr1(ld, -1.f);
+                const int pi = __float_as_int(dpp_wave_shr1(__int_as_float(li), 0.f));
+                const bool pgt = pd > cd;
+                ld = gt ? (pgt ? pd : cd) : ld;
+                li = gt ? (pgt ? pi : ci) : li;
+                kth = __shfl(ld, k - 1);
+            }
+        }
+    }
+    if (active && lane < k) {
+        idx[((long)b * M + m) * k + lane] = li;
+        if (d2out) d2out[((long)b * M + m) * k + lane] = ld;
+    }
+    if (active && wout) {   // three-NN weights (k == 3): w_j = (1/(d2_j+1e-8)) / sum
+        const float r = __fdiv_rn(1.0f, __fadd_rn(ld, 1e-8f));
+        const float r0 = __shfl(r, 0), r1 = __shfl(r, 1), r2 = __shfl(r, 2);
+        const float s = __fadd_rn(__fadd_rn(r0, r1), r2);
+        if (lane < 3) wout[((long)b * M + m) * 3 + lane] = __fdiv_rn(r, s);
+    }
+}
+
+static int knn_launch(const float *query, const float *ref, int B, int M, int N, int k, int32_t *idx, float *d2,
+                      float *w, hipStream_t stream) {
+    const long blocks = ((long)M + KNN_WAVES - 1) / KNN_WAVES;
+    P2N_REQUIRE(B <= 65535, "p2n_knn: B > 65535");
+    hipLaunchKernelGGL(p2n_knn_kernel, dim3((unsigned)blocks, B, 1), dim3(KNN_WAVES * 64), 0, stream, query, ref, M, N,
+                       k, idx, d2, w);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+extern "C" int p2n_knn(const float *query, const float *ref, int B, int M, int N, int k, int32_t *idx, float *d2,
+                       void *stream) {
+    P2N_REQUIRE(B >= 0 && M >= 0 && N >= 1, "p2n_knn: bad shape B=%d M=%d N=%d", B, M, N);
+    P2N_REQUIRE(k >= 1 && k <= 64, "p2n_knn: k=%d not in [1,64]", k);
+    P2N_REQUIRE(k <= N, "p2n_knn: k=%d exceeds the number of reference points %d", k, N);
+    if (B == 0 || M == 0) return P2N_OK;
+    P2N_REQUIRE(query && ref && idx, "p2n_knn: null pointer");
+    return knn_launch(query, ref, B, M, N, k, idx, d2, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int p2n_three_nn(const float *unknown, const float *known, int B, int n, int m, float *dist2, int32_t *idx,
+                            float *weight, void *stream) {
+    P2N_REQUIRE(B >= 0 && n >= 0, "p2n_three_nn: bad shape B=%d n=%d", B, n);
+    P2N_REQUIRE(m >= 3, "p2n_three_nn: need at least 3 known points, got %d", m);
+    if (B == 0 || n == 0) return P2N_OK;
+    P2N_REQUIRE(unknown && known && dist2 && idx, "p2n_three_nn: null pointer");
+    return knn_launch(unknown, known, B, n, m, 3, idx, dist2, weight, (hipStream_t)stream);
+}
+
+// =========================================================================== gather / interpolate
+// HBM-bound streaming kernels: indices (and weights) are read once per output
+// column and reused across a chunk of channels; writes are contiguous along the
+// fastest output dimension.
+#define GG_CH 8
+
+// Indices are the caller's contract (0 <= i < limit).  A wild index would fault the
+// GPU, so it is clamped instead of trusted; the result for such an index is undefined.
+__device__ __forceinline__ int clamp_idx(int i, int limit) { return i < 0 ? 0 : (i >= limit ? limit - 1 : i); }
+
+__global__ __launch_bounds__(256) void p2n_group_gather_kernel(const float *__restrict__ feat,
+                                                              const int32_t *__restrict__ idx, int C, int N, long MS,
+                                                              float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= MS) return;
+    const int i = clamp_idx(idx[(long)b * MS + j], N);
+    const int c0 = blockIdx.y * GG_CH;
+#pragma unroll
+    for (int c = 0; c < GG_CH; ++c)
+        if (c0 + c < C) out[((long)b * C + c0 + c) * MS + j] = feat[((long)b * C + c0 + c) * N + i];
+}
+
+__global__ __launch_bounds__(256) void p2n_group_gather_bwd_kernel(const float *__restrict__ gout,
+                                                                  const int32_t *__restrict__ idx, int C, int N,
+                                                                  long MS, float *__restrict__ gfeat) {
+    const int b = blockIdx.z;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= MS) return;
+    const int i = clamp_idx(idx[(long)b * MS + j], N);
+    const int c0 = blockIdx.y * GG_CH;
+#pragma unroll
+    for (int c = 0; c < GG_CH; ++c)
+        if (c0 + c < C) atomicAdd(&gfeat[((long)b * C + c0 + c) * N + i], gout[((long)b * C + c0 + c) * MS + j]);
+}
+
+extern "C" int p2n_group_gather(const float *feat, const int32_t *idx, int B, int C, int N, int M, int ns, float *out,
+                                void *stream) {
+    P2N_REQUIRE(B >= 0 && C >= 0 && N >= 1 && M >= 0 && ns >= 0, "p2n_group_gather: bad shape");
+    const long MS = (long)M * ns;
+    if (B == 0 || C == 0 || MS == 0) return P2N_OK;
+    P2N_REQUIRE(feat && idx && out, "p2n_group_gather: null pointer");
+    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_group_gather: B or C too large");
+    hipLaunchKernelGGL(p2n_group_gather_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
+                       dim3(256), 0, (hipStream_t)stream, feat, idx, C, N, MS, out);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+extern "C" int p2n_group_gather_bwd(const float *gout, const int32_t *idx, int B, int C, int N, int M, int ns,
+                                    float *gfeat, void *stream) {
+    P2N_REQUIRE(B >= 0 && C >= 0 && N >= 1 && M >= 0 && ns >= 0, "p2n_group_gather_bwd: bad shape");
+    const long MS = (long)M * ns;
+    if (B == 0 || C == 0) return P2N_OK;
+    P2N_REQUIRE(gfeat, "p2n_group_gather_bwd: null pointer");
+    P2N_CHECK_HIP(hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * N, (hipStream_t)stream));
+    if (MS == 0) return P2N_OK;
+    P2N_REQUIRE(gout && idx, "p2n_group_gather_bwd: null pointer");
+    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_group_gather_bwd: B or C too large");
+    hipLaunchKernelGGL(p2n_group_gather_bwd_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
+                       dim3(256), 0, (hipStream_t)stream, gout, idx, C, N, MS, gfeat);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+__global__ __launch_bounds__(256) void p2n_three_interp_kernel(const float *__restrict__ feat,
+                                                              const int32_t *__restrict__ idx,
+                                                              const float *__restrict__ w, int C, int m, int n,
+                                                              float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *id = idx + ((long)b * n + i) * 3;
+    const float *ww = w + ((long)b * n + i) * 3;
+    const int i0 = clamp_idx(id[0], m), i1 = clamp_idx(id[1], m), i2 = clamp_idx(id[2], m);
+    const float w0 = ww[0], w1 = ww[1], w2 = ww[2];
+    const int c0 = blockIdx.y * GG_CH;
+#pragma unroll
+    for (int c = 0; c < GG_CH; ++c)
+        if (c0 + c < C) {
+            const float *f = feat + ((long)b * C + c0 + c) * m;
+            out[((long)b * C + c0 + c) * n + i] =
+                __fadd_rn(__fadd_rn(__fmul_rn(w0, f[i0]), __fmul_rn(w1, f[i1])), __fmul_rn(w2, f[i2]));
+        }
+}
+
+__global__ __launch_bounds__(256) void p2n_three_interp_bwd_kernel(const float *__restrict__ gout,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ w, int C, int m, int n,
+                                                                  float *__restrict__ gfeat) {
+    const int b = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *id = idx + ((long)b * n + i) * 3;
+    const float *ww = w + ((long)b * n + i) * 3;
+    const int i0 = clamp_idx(id[0], m), i1 = clamp_idx(id[1], m), i2 = clamp_idx(id[2], m);
+    const float w0 = ww[0], w1 = ww[1], w2 = ww[2];
+    const int c0 = blockIdx.y * GG_CH;
+#pragma unroll
+    for (int c = 0; c < GG_CH; ++c)
+        if (c0 + c < C) {
+            const float g = gout[((long)b * C + c0 + c) * n + i];
+            float *f = gfeat + ((long)b * C + c0 + c) * m;
+            atomicAdd(&f[i0], g * w0);
+            atomicAdd(&f[i1], g * w1);
+            atomicAdd(&f[i2], g * w2);
+        }
+}
+
+extern "C" int p2n_three_interpolate(const float *feat, const int32_t *idx, const float *weight, int B, int C, int m,
+                                     int n, float *out, void *stream) {
+    P2N_REQUIRE(B >= 0 && C >= 0 && m >= 1 && n >= 0, "p2n_three_interpolate: bad shape");
+    if (B == 0 || C == 0 || n == 0) return P2N_OK;
+    P2N_REQUIRE(feat && idx && weight && out, "p2n_three_interpolate: null pointer");
+    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_three_interpolate: B or C too large");
+    hipLaunchKernelGGL(p2n_three_interp_kernel, dim3((n + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
+                       (hipStream_t)stream, feat, idx, weight, C, m, n, out);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+extern "C" int p2n_three_interpolate_bwd(const float *gout, const int32_t *idx, const float *weight, int B, int C,
+                                         int m, int n, float *gfeat, void *stream) {
+    P2N_REQUIRE(B >= 0 && C >= 0 && m >= 1 && n >= 0, "p2n_three_interpolate_bwd: bad shape");
+    if (B == 0 || C == 0) return P2N_OK;
+    P2N_REQUIRE(gfeat, "p2n_three_interpolate_bwd: null pointer");
+    P2N_CHECK_HIP(hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * m, (hipStream_t)stream));
+    if (n == 0) return P2N_OK;
+    P2N_REQUIRE(gout && idx && weight, "p2n_three_interpolate_bwd: null pointer");
+    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_three_interpolate_bwd: B or C too large");
+    hipLaunchKernelGGL(p2n_three_interp_bwd_kernel, dim3((n + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
+                       (hipStream_t)stream, gout, idx, weight, C, m, n, gfeat);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}

@@ -108,6 +108,8 @@ class Point2Net(nn.Module):
     def forward(self, x):
         if x.dim() != 3 or x.size(2) != self.feature_dim:
             raise ValueError(f"expected x of shape (B, N, {self.feature_dim}), got {tuple(x.shape)}")
+        if x.is_cuda and x.dtype != torch.float32:
+            raise TypeError(f"the HIP path computes in float32, got {x.dtype}")
         if not x.is_cuda:
             # CPU: stock PyTorch ops, reference point2net.py:75-87
             f1, f2, f3, global_f = self.encoder(x)
