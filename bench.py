@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Point2Net backbone forward, points/s at N=8192, B=16 per GPU
+(BASELINE.json `metric`, configs[1]), scene-sharded over the GPUs of one node.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one eval forward of the drop-in module (`src.models.point2net.Point2Net`,
+trained weights from tests/golden/weights.npz) over one resident synthetic
+ScanNet-shaped batch of 16 x 8192 points.  Every rank owns its own batch and there is
+no data-path collective (eval clouds are independent: SURVEY.md section 8e), so
+scaling is weak and `value` = points all ranks processed / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      for the dominant kernel, from HIP events recorded around every kernel
+                launch inside the timed region (libp2n's p2n_profile_* hooks)
+  cpu_baseline  the CPU oracle (oracle/p2n_oracle.c, a port) timed on this host
+  cpu_torch     the same drop-in module run on the host with stock PyTorch ops
+  fps           farthest-point sampling of one 40k-point scene (the metric's second half)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+B_PER_GPU = 16
+N_POINTS = 8192
+# algorithmic FLOPs per point (DESIGN.md "Algorithmic work"): 2 * MACs of the layers a
+# kernel runs, with the global half of head layer 6 folded to a per-cloud bias
+FLOP_PER_PT = {"encoder": 2 * 127360, "head": 2 * 106496}
+FLOP_PER_PT_STEP = 467712          # SURVEY.md section 8d (598,784 as the reference writes it)
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+KERNEL_IDS = {"encoder": 0, "mid": 1, "head": 2, "fps": 3}
+
+
+def load_model(device):
+    from src.models.point2net import Point2Net
+    sd = np.load(os.path.join(REPO, "tests", "golden", "weights.npz"))
+    m = Point2Net(feature_dim=6, embedding_dim=64)
+    m.load_state_dict({k: torch.from_numpy(sd[k]) for k in sd.files}, strict=True)
+    return m.to(device).eval()
+
+
+def collect_kernel_ms():
+    from pointcloudsegmentation_amd import _lib
+    ms = (ctypes.c_float * 32)()
+    cnt = (ctypes.c_int * 32)()
+    _lib.check(_lib.lib().p2n_profile_collect(32, ms, cnt), "p2n_profile_collect")
+    return {k: (ms[i] / cnt[i] if cnt[i] else None, cnt[i]) for k, i in KERNEL_IDS.items()}
+
+
+def cpu_baselines(x_np):
+    """Bounded CPU legs on rank 0: the oracle port (all OpenMP threads) and the drop-in
+    module on stock PyTorch CPU ops.  Sample = the full 16 x 8192 batch, once."""
+    from oracle import oracle
+    from pointcloudsegmentation_amd.params import flatten_numpy
+    from src.models.point2net import Point2Net
+    sd = np.load(os.path.join(REPO, "tests", "golden", "weights.npz"))
+    params = flatten_numpy({k: sd[k] for k in sd.files})
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    oracle.forward_eval(x_np[:1, :256], params)          # warm (loads the .so, spins up OpenMP)
+    t = time.perf_counter()
+    oracle.forward_eval(x_np, params)
+    dt = time.perf_counter() - t
+    port = {"value": x_np.shape[0] * x_np.shape[1] / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"{x_np.shape[0]}x{x_np.shape[1]} points (one full step), oracle/p2n_oracle.c, "
+                      f"OpenMP over points, fp32 with double accumulation, {dt:.2f} s"}
+    torch.set_num_threads(threads)
+    m = Point2Net(6, 64)
+    m.load_state_dict({k: torch.from_numpy(sd[k]) for k in sd.files})
+    m.eval()
+    xt = torch.from_numpy(x_np)
+    with torch.no_grad():
+        m(xt[:2])
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            m(xt)
+            ts.append(time.perf_counter() - t)
+    dt = sorted(ts)[1]
+    tcpu = {"value": x_np.shape[0] * x_np.shape[1] / dt, "unit": "points/s", "cores": threads, "kind": "torch-cpu",
+            "sample": f"drop-in module on CPU tensors (stock Conv1d/BatchNorm1d/ReLU = the reference's op "
+                      f"sequence), median of 3 full steps, {dt:.3f} s"}
+    return port, tcpu
+
+
+def fps_leg(device):
+    """FPS of one 40,000-point scene to 10,000 samples: per-call ms (HIP events)."""
+    from pointcloudsegmentation_amd import ops
+    from pointcloudsegmentation_amd.synth import make_batch
+    xyz = torch.from_numpy(np.ascontiguousarray(make_batch(1, 40000, 7)[:, :, :3])).to(device)
+    npoint = 10000
+    ops.farthest_point_sample(xyz, npoint)
+    torch.cuda.synchronize(device)
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.farthest_point_sample(xyz, npoint)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / reps
+    return {"ms_per_40k_scene": ms, "npoint": npoint, "us_per_sample": 1e3 * ms / npoint,
+            "status": ops.fps_status(device)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-fps", action="store_true", help="skip the FPS leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from pointcloudsegmentation_amd import _lib
+    from pointcloudsegmentation_amd.synth import make_batch
+
+    model = load_model(device)
+    x_np = make_batch(B_PER_GPU, N_POINTS, seed=1000 + rank)      # every rank: its own scenes
+    x = torch.from_numpy(x_np).to(device)
+    lib = _lib.lib()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(x)
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        lib.p2n_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x)
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+    kernels = collect_kernel_ms()
+    lib.p2n_profile_enable(0)
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert y.shape == (B_PER_GPU, N_POINTS, 64) and bool(torch.isfinite(y).all())
+
+    if rank == 0:
+        pts_step = B_PER_GPU * N_POINTS
+        value = world * pts_step * args.steps / elapsed
+        dom = max(("encoder", "head"), key=lambda k: kernels[k][0] or 0.0)
+        dom_ms = kernels[dom][0]
+        achieved = FLOP_PER_PT[dom] * pts_step / (dom_ms * 1e-3) / 1e12
+        out = {
+            "metric": "backbone fwd points/sec (N=8192,B=16)",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Point2Net eval forward, B=16 x N=8192 ScanNet-shaped clouds per GPU "
+                                   "(BASELINE.json configs[1]), trained weights, scene-sharded, no collective",
+                       "global_batch": world * B_PER_GPU, "points_per_cloud": N_POINTS, "parallelism": f"scenes x{world}"},
+            "per_gpu_value": value / world,
+            "step_tflops_algorithmic": FLOP_PER_PT_STEP * pts_step / (elapsed / args.steps) / 1e12,
+            "kernels_ms": {k: v[0] for k, v in kernels.items() if v[1]},
+            "roofline": {"bound": "mfma", "kernel": f"p2n_{dom}_kernel", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None,
+                         "note": f"{FLOP_PER_PT[dom]} algorithmic FLOP/pt x {pts_step} pts per launch / "
+                                 f"{dom_ms:.4f} ms mean launch (HIP events on the launch stream, {kernels[dom][1]} launches)"},
+        }
+        if world == 1:
+            if not args.no_fps:
+                out["fps"] = fps_leg(device)
+            if not args.no_cpu:
+                port, tcpu = cpu_baselines(x_np)
+                out["cpu_baseline"] = port
+                out["cpu_torch"] = tcpu
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,14 @@ int p2n_three_interpolate(const float *feat, const int32_t *idx, const float *we
 int p2n_three_interpolate_bwd(const float *grad_out, const int32_t *idx, const float *weight,
                               int B, int C, int m, int n, float *grad_feat, void *stream);
 
+/* ---- measurement aid (no counterpart in the reference) ---------------------
+ * While enabled, every kernel launch is bracketed by HIP events on its stream.
+ * p2n_profile_collect synchronises and fills, per kernel id (0 encoder, 1 mid,
+ * 2 head, 3 fps, 5 knn), the summed milliseconds and the number of launches since
+ * the last collect.  HOST pointers.  Not thread-safe; off by default. */
+int p2n_profile_enable(int on);
+int p2n_profile_collect(int max_ids, float *ms_sum_host, int *count_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,9 +75,19 @@ static void split_params(const float *p, int F, int E, layer_t L[NLAYER]) {
  * summation orders. */
 static void point_layer(const layer_t *L, int cin, int cout, const float *in, float *out, int bn_relu) {
     for (int o = 0; o < cout; ++o) {
-        double acc = 0.0;
+        /* four interleaved partial sums (a fixed association, so results are
+         * reproducible) keep the double-precision adds off one dependency chain */
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         const float *w = L->W + (long)o * cin;
-        for (int k = 0; k < cin; ++k) acc += (double)w[k] * (double)in[k];
+        int k = 0;
+        for (; k + 3 < cin; k += 4) {
+            a0 += (double)w[k] * (double)in[k];
+            a1 += (double)w[k + 1] * (double)in[k + 1];
+            a2 += (double)w[k + 2] * (double)in[k + 2];
+            a3 += (double)w[k + 3] * (double)in[k + 3];
+        }
+        for (; k < cin; ++k) a0 += (double)w[k] * (double)in[k];
+        const double acc = (a0 + a1) + (a2 + a3);
         float y = (float)(acc + (double)L->b[o]);
         if (bn_relu) {
             float inv = 1.0f / sqrtf(L->var[o] + BN_EPS);

@@ -8,6 +8,12 @@ import ctypes
 import os
 import subprocess
 
+# One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 and libp2n_hip.so
+# NEEDs the same soname, so torch has to be loaded first for the dynamic loader to hand
+# our library torch's runtime (a second runtime from /opt/rocm sees no device and does
+# not share streams or allocations with torch).
+import torch  # noqa: F401  (must precede ctypes.CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libp2n_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -39,6 +45,8 @@ SIGNATURES = {
     "p2n_three_nn": (c_int, [c_f, c_f, c_int, c_int, c_int, c_f, c_i, c_f, c_vp]),
     "p2n_three_interpolate": (c_int, [c_f, c_i, c_f, c_int, c_int, c_int, c_int, c_f, c_vp]),
     "p2n_three_interpolate_bwd": (c_int, [c_f, c_i, c_f, c_int, c_int, c_int, c_int, c_f, c_vp]),
+    "p2n_profile_enable": (c_int, [c_int]),
+    "p2n_profile_collect": (c_int, [c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
 }
 
 

@@ -71,6 +71,19 @@ static inline P2nLayout p2n_make_layout(int F, int E) {
     return L;
 }
 
+// ---- optional per-kernel timing (p2n_api.hip) ----
+#define P2N_K_ENCODER 0
+#define P2N_K_MID 1
+#define P2N_K_HEAD 2
+#define P2N_K_FPS 3
+#define P2N_K_BALL 4
+#define P2N_K_KNN 5
+#define P2N_K_GATHER 6
+#define P2N_K_INTERP 7
+#define P2N_K_COUNT 32
+int p2n_prof_begin(int kernel_id, hipStream_t s);
+void p2n_prof_end(int slot, hipStream_t s);
+
 // ---- error plumbing (p2n_api.hip) ----
 void p2n_set_error(const char *fmt, ...);
 #define P2N_CHECK_HIP(expr)                                                          \

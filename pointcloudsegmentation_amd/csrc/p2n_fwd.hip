@@ -486,14 +486,18 @@ extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, cons
     ea.N = N; ea.F = F; ea.tiles = tiles; ea.stream = L.enc_stream;
     ea.tab = L.scale[0]; ea.tab_n = (int)(L.scale[6] - L.scale[0]);
     for (int l = 0; l < 6; ++l) { ea.scale[l] = (int)(L.scale[l] - L.scale[0]); ea.shift[l] = (int)(L.shift[l] - L.scale[0]); }
+    int ps = p2n_prof_begin(P2N_K_ENCODER, stream);
     if (f1 || f2 || f3)
         hipLaunchKernelGGL(p2n_encoder_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, stream, ea);
     else
         hipLaunchKernelGGL(p2n_encoder_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, stream, ea);
+    p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
+    ps = p2n_prof_begin(P2N_K_MID, stream);
 
     hipLaunchKernelGGL(p2n_mid_kernel, dim3(B, 8), dim3(256), 0, stream, partial, tiles, packed, L.w6g, L.scale[6],
                        L.shift[6], shift6c, global_f);
+    p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
 
     if (!emb) return P2N_OK;   // encoder-only call (reference point2net.py:36-48)
@@ -508,7 +512,9 @@ extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, cons
         P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_head_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    ps = p2n_prof_begin(P2N_K_HEAD, stream);
     hipLaunchKernelGGL(p2n_head_kernel, dim3((unsigned)ntiles), dim3(256), lds, stream, ha);
+    p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }

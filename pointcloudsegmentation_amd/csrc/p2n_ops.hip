@@ -178,7 +178,9 @@ extern "C" size_t p2n_fps_workspace_bytes(int B, int N, int M) {
 
 template <int PPT>
 static void fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
+    const int ps = p2n_prof_begin(P2N_K_FPS, s);
     hipLaunchKernelGGL(p2n_fps_kernel<PPT>, dim3(nb * a.G), dim3(FPS_THREADS), 0, s, a);
+    p2n_prof_end(ps, s);
 }
 
 extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, void *workspace,
@@ -372,8 +374,10 @@ static int knn_launch(const float *query, const float *ref, int B, int M, int N,
                       float *w, hipStream_t stream) {
     const long blocks = ((long)M + KNN_WAVES - 1) / KNN_WAVES;
     P2N_REQUIRE(B <= 65535, "p2n_knn: B > 65535");
+    const int ps = p2n_prof_begin(P2N_K_KNN, stream);
     hipLaunchKernelGGL(p2n_knn_kernel, dim3((unsigned)blocks, B, 1), dim3(KNN_WAVES * 64), 0, stream, query, ref, M, N,
                        k, idx, d2, w);
+    p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
