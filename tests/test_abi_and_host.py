@@ -1,0 +1,105 @@
+"""CPU: the C-ABI library loads and exports every symbol include/p2n.h declares (no
+compute calls without a GPU), and the host module is a drop-in for the reference's
+module (state_dict keys, strict checkpoint load, CPU forward = golden embeddings)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, assert_close_to_max, golden
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "p2n.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(p2n_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pointcloudsegmentation_amd import _lib
+    lib = _lib.lib()
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/p2n.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.p2n_version() >= 100
+    assert lib.p2n_param_count(6, 64) == 305856 - 0      # 303,296 learnables + 8 BN layers x 2 running stats
+    assert lib.p2n_packed_param_count(9, 64) == -1         # feature_dim > 8 unsupported: says so, no UB
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    """Shape errors are reported by the library before anything touches a device."""
+    from pointcloudsegmentation_amd import _lib
+    lib = _lib.lib()
+    assert lib.p2n_forward_eval(None, 1, 10, 9, 64, None, None, None, None, None, None, None, 0, None) == 1
+    assert b"feature_dim" in lib.p2n_last_error()
+    assert lib.p2n_knn(None, None, 1, 5, 10, 11, None, None, None) == 1
+    assert b"exceeds" in lib.p2n_last_error()
+    assert lib.p2n_fps(None, 1, 10, 4, 10, None, None, 0, None) == 1
+    assert lib.p2n_three_nn(None, None, 1, 5, 2, None, None, None, None) == 1
+    assert lib.p2n_forward_eval_workspace_bytes(16, 8192, 6, 64) == 4 * (1024 * 4 * 8192 + 1024 * 256 + 16 * 256)
+
+
+def test_param_layout_matches_library():
+    from pointcloudsegmentation_amd import _lib, params
+    for F, E in [(6, 64), (3, 32), (8, 256)]:
+        assert params.param_count(F, E) == _lib.lib().p2n_param_count(F, E)
+    assert len(params.flat_order()) == 50      # 58 state_dict keys minus 8 num_batches_tracked
+
+
+def test_state_dict_is_the_reference_checkpoint_layout(ref_weights):
+    from src.models.point2net import Point2Net, PointNet2Encoder
+    m = Point2Net(feature_dim=6, embedding_dim=64)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref_weights.keys())           # same 58 keys, same order
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref_weights[k].shape), k
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref_weights.items()}, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 303296
+    assert isinstance(m.encoder, PointNet2Encoder)
+
+
+def test_cpu_forward_is_stock_pytorch_and_matches_golden(ref_weights):
+    from src.models.point2net import Point2Net
+    m = Point2Net(6, 64)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref_weights.items()})
+    m.eval()
+    g = golden("eval_b2_n1000_s0.npz")
+    with torch.no_grad():
+        x = torch.from_numpy(g["x"])
+        emb = m(x)
+        f1, f2, f3, gf = m.encoder(x)
+    assert emb.shape == (2, 1000, 64)
+    assert_close_to_max(emb.numpy(), g["emb"], 1e-6, "emb")
+    assert_close_to_max(f3.numpy(), g["f3"], 1e-6, "f3")
+    assert_close_to_max(gf.numpy(), g["global_f"], 1e-6, "global_f")
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 10, 5))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No silent fallback: with the .so absent the binding raises."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from pointcloudsegmentation_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "try:\n    _lib.lib()\nexcept _lib.P2nError as e:\n    print('RAISED', 'no fallback' in str(e))\n"
+    ) % (REPO, str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package or src/ may name it."""
+    for root in ("pointcloudsegmentation_amd", "src"):
+        for dirpath, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                    assert "libp2n_oracle" not in text, f
