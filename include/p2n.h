@@ -64,6 +64,26 @@ int p2n_forward_eval(const float *x, int B, int N, int feature_dim, int embeddin
                      float *f1, float *f2, float *f3,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- training path -------------------------------------------------------
+ * Train-mode forward (reference point2net.py:36-48,67-87 with model.train(),
+ * reference train.py:109,124): BatchNorm uses batch statistics (biased variance),
+ * updates running_mean/var in place with `momentum` (unbiased variance), and the
+ * activations needed by the backward are kept in `workspace`.
+ * params_host: HOST array of 50 DEVICE pointers in raw-parameter order
+ *   (W, bias, [bn.weight, bn.bias, running_mean, running_var]) per layer.
+ * p2n_train_backward (reference train.py:131, loss.backward()) consumes the same,
+ * untouched workspace plus gemb = dL/d emb (B,N,E) and overwrites the 34 gradient
+ * tensors grads_host points at, in the order (W, bias, [bn.weight, bn.bias]) per layer.
+ * Weight gradients are summed with fp32 atomics (order not reproducible). */
+size_t p2n_train_workspace_bytes(int B, int N, int feature_dim, int embedding_dim);
+int p2n_train_forward(const float *x, int B, int N, int feature_dim, int embedding_dim,
+                      const void *const *params_host, float momentum, float *emb, float *global_f,
+                      float *f1, float *f2, float *f3,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int p2n_train_backward(const float *x, const float *gemb, int B, int N, int feature_dim, int embedding_dim,
+                       const void *const *params_host, void *const *grads_host,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- point-set operators (named by BASELINE.json north_star; the reference has
  * none of them -- SURVEY.md section 0 -- so oracle/p2n_oracle.c is their spec:
  * fp32 squared distance ((dx*dx+dy*dy)+dz*dz) without fma, lowest index wins

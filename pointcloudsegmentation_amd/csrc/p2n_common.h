@@ -80,6 +80,8 @@ static inline P2nLayout p2n_make_layout(int F, int E) {
 #define P2N_K_KNN 5
 #define P2N_K_GATHER 6
 #define P2N_K_INTERP 7
+#define P2N_K_TRAIN_GEMM 8
+#define P2N_K_TRAIN_WGRAD 9
 #define P2N_K_COUNT 32
 int p2n_prof_begin(int kernel_id, hipStream_t s);
 void p2n_prof_end(int slot, hipStream_t s);

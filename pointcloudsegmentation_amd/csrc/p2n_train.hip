@@ -1,0 +1,680 @@
+// Training path of Point2Net for gfx950 (MI355X): train-mode BatchNorm forward and the
+// full backward, as exact-fp32 MFMA GEMMs with the elementwise work fused into the
+// operand loaders.  Replaces, for GPU tensors, what autograd records for reference
+// point2net.py:36-48 and :67-87 when the model is in train() mode (reference
+// train.py:109,124,131): Conv1d(k=1) -> BatchNorm1d(batch statistics, biased variance
+// for normalisation, unbiased for running_var, momentum 0.1) -> ReLU, the global max
+// with its arg-max backward, the concat (folded: W6.[f3;g] = W6a.f3 + W6b.g), the head.
+//
+// Data layout: every saved tensor is channel-major (C, Ppad) over the flattened batch
+// P = B*N (Ppad = P rounded up to 128), i.e. the reference's (B,C,N) with the batch
+// folded into the row.  Only PRE-BatchNorm conv outputs z_l are stored; BN+ReLU (forward)
+// and the whole BatchNorm/ReLU backward are recomputed inside the loaders of the next
+// GEMM from z_l and five per-channel constants, so an activation is written once and
+// read by exactly the kernels that need it:
+//   forward  l: z_l = W_l . relu(bn(z_{l-1})) + b_l          (layer kernel, B operand loader)
+//            stats: per-row pivot-shifted sum / sum of squares -> mean, rstd, running stats
+//   backward l: sums of dy, dy*zhat per row                   (stats kernel)
+//            dW_l = dz_l . a_{l-1}^T   (wgrad kernel: k = points, both operands row loaders)
+//            da_{l-1} = W_l^T . dz_l   (layer kernel again, dz recomputed in the loader)
+// MFMA orientation as in p2n_fwd.hip: D = W.X, lane = point, registers = channels.
+#include "p2n_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define BN_EPS 1e-5
+
+enum { LD_X = 0, LD_BNRELU = 1, LD_BNBWD = 2, LD_EMBGRAD = 3 };
+
+// ---------------------------------------------------------------- weight image
+// img[ct][G][lane][j] = M[32ct + (lane&31)][8G + 4(lane>>5) + j], M = W (rows=Cout) or
+// W^T (rows=Cin); zero outside the real extent.
+__global__ void p2n_pack_w_kernel(const float *__restrict__ W, int ldw, int col0, int rows_real, int k_real, int trans,
+                                  float *__restrict__ img, int CT, int G) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)CT * G * 256) return;
+    const int e = (int)(i & 255), lane = e >> 2, j = e & 3;
+    const long f = i >> 8;
+    const int ct = (int)(f / G), g = (int)(f % G);
+    const int row = 32 * ct + (lane & 31), k = 8 * g + 4 * (lane >> 5) + j;
+    float v = 0.f;
+    if (row < rows_real && k < k_real) v = trans ? W[(long)k * ldw + col0 + row] : W[(long)row * ldw + col0 + k];
+    img[i] = v;
+}
+
+// ---------------------------------------------------------------- layer GEMM (forward / dgrad)
+struct LayerArgs {
+    const float *in0;         // LD_X: x (P,F); LD_BNRELU: z_prev (K,Ppad); LD_BNBWD: da (K,Ppad); LD_EMBGRAD: gemb (P,E)
+    const float *in1;         // LD_BNBWD: z (K,Ppad)
+    const float *wimg;        // [CT][G][64][4]
+    const float *bias;        // per output row, may be NULL
+    const float *bias_cloud;  // [B][rows] added on top, may be NULL (layer 6: W6b.g)
+    const float *tab;         // per-k constants: BNRELU {s,t}[K]; BNBWD {s,t,A1,A2,A3}[K]
+    float *out;               // (rows,Ppad) channel-major, or (P,ldo) point-major when OUT_PM
+    int K, CT, rows, P, Ppad, N, ld;   // ld: F for LD_X, E for LD_EMBGRAD / OUT_PM
+};
+
+template <int MODE, int KT, bool OUT_PM>
+__global__ __launch_bounds__(256) void p2n_train_layer_kernel(LayerArgs A) {
+    __shared__ __attribute__((aligned(16))) float tab[5 * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const long pg = ((long)blockIdx.x * 4 + wave) * 32 + p;
+    const bool valid = pg < A.P;
+    constexpr int KP = KT * 32;   // padded reduction length
+    if (MODE == LD_BNRELU || MODE == LD_BNBWD) {
+        const int nt = (MODE == LD_BNRELU ? 2 : 5);
+        for (int i = threadIdx.x; i < nt * KP; i += 256) {
+            const int which = i / KP, k = i - which * KP;
+            tab[i] = k < A.K ? A.tab[which * A.K + k] : 0.f;
+        }
+        __syncthreads();
+    }
+    f32x16 in[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k0 = 32 * kt + 8 * g + 4 * h;
+            if (MODE == LD_X) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    in[kt][4 * g + j] = (valid && k0 + j < A.K) ? A.in0[pg * A.ld + k0 + j] : 0.f;
+            } else if (MODE == LD_EMBGRAD) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    in[kt][4 * g + j] = (valid && k0 + j < A.K) ? A.in0[pg * A.ld + k0 + j] : 0.f;
+            } else if (MODE == LD_BNRELU) {
+                const f32x4 s = *reinterpret_cast<const f32x4 *>(&tab[k0]);
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(&tab[KP + k0]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+                    if (valid && k0 + j < A.K) v = fmaxf(fmaf(A.in0[(long)(k0 + j) * A.Ppad + pg], s[j], t[j]), 0.f);
+                    in[kt][4 * g + j] = v;
+                }
+            } else {   // LD_BNBWD: dz = A1*dy + A2 + A3*z, dy = da masked by relu(bn(z)) > 0
+                const f32x4 s = *reinterpret_cast<const f32x4 *>(&tab[k0]);
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(&tab[KP + k0]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&tab[2 * KP + k0]);
+                const f32x4 a2 = *reinterpret_cast<const f32x4 *>(&tab[3 * KP + k0]);
+                const f32x4 a3 = *reinterpret_cast<const f32x4 *>(&tab[4 * KP + k0]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+                    if (valid && k0 + j < A.K) {
+                        const float z = A.in1[(long)(k0 + j) * A.Ppad + pg];
+                        const float da = A.in0[(long)(k0 + j) * A.Ppad + pg];
+                        const float dy = fmaf(z, s[j], t[j]) > 0.f ? da : 0.f;
+                        v = fmaf(a3[j], z, fmaf(a1[j], dy, a2[j]));
+                    }
+                    in[kt][4 * g + j] = v;
+                }
+            }
+        }
+    const int cloud = valid ? (int)(pg / A.N) : 0;
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(A.wimg) + lane;
+#pragma unroll 1
+    for (int ct = 0; ct < A.CT; ++ct) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = wl[(long)((ct * KT + kt) * 4 + g) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], in[kt][4 * g + j], acc);
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r0 = 32 * ct + 8 * g + 4 * h;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[4 * g + j];
+                if (r0 + j < A.rows) {
+                    if (A.bias) v += A.bias[r0 + j];
+                    if (A.bias_cloud) v += A.bias_cloud[(long)cloud * A.rows + r0 + j];
+                }
+                o[j] = v;
+            }
+            if (OUT_PM) {
+                if (valid)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (r0 + j < A.rows) A.out[pg * A.ld + r0 + j] = o[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0 + j < A.rows) A.out[(long)(r0 + j) * A.Ppad + pg] = o[j];   // pad columns too (finite)
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- wgrad: dW = dz . a^T over points
+struct WgArgs {
+    const float *a0;    // A side: LD_BNBWD: da (rows,Ppad); LD_EMBGRAD: gemb (P,E)
+    const float *a1;    // A side: z (rows,Ppad)
+    const float *atab;  // {s,t,A1,A2,A3}[rows]
+    const float *b0;    // B side: LD_BNRELU: z_prev (cols,Ppad); LD_X: x (P,F)
+    const float *btab;  // {s,t}[cols]
+    float *dW;          // (rows, ldw) row-major, accumulated with atomics (zeroed by the caller)
+    int rows, cols, ldw, P, Ppad, ld_a, ld_b, slice, ntc;   // ntc = column tiles
+};
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void p2n_wgrad_kernel(WgArgs A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tr = blockIdx.y / A.ntc, tc = blockIdx.y % A.ntc;
+    const long s0 = ((long)blockIdx.x * 4 + wave) * A.slice;
+    long s1 = s0 + A.slice;
+    if (s1 > A.P) s1 = A.P;
+    const int row = 32 * tr + r, col = 32 * tc + r;
+    const bool rok = row < A.rows, cok = col < A.cols;
+    float as = 0, at = 0, a1 = 0, a2 = 0, a3 = 0, bs = 0, bt = 0;
+    if (AMODE == LD_BNBWD && rok) {
+        as = A.atab[row]; at = A.atab[A.rows + row]; a1 = A.atab[2 * A.rows + row];
+        a2 = A.atab[3 * A.rows + row]; a3 = A.atab[4 * A.rows + row];
+    }
+    if (BMODE == LD_BNRELU && cok) { bs = A.btab[col]; bt = A.btab[A.cols + col]; }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (long p0 = s0; p0 < s1; p0 += 8) {
+        const long p = p0 + 4 * h;
+        float av[4], bv[4];
+        if (AMODE == LD_BNBWD) {
+            f32x4 da = {0, 0, 0, 0}, z = {0, 0, 0, 0};
+            if (rok) {   // slice starts are multiples of 8 and Ppad of 128: the 16-byte loads stay in the row
+                da = *reinterpret_cast<const f32x4 *>(A.a0 + (long)row * A.Ppad + p);
+                z = *reinterpret_cast<const f32x4 *>(A.a1 + (long)row * A.Ppad + p);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dy = fmaf(z[j], as, at) > 0.f ? da[j] : 0.f;
+                av[j] = (rok && p + j < s1) ? fmaf(a3, z[j], fmaf(a1, dy, a2)) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = (rok && p + j < s1) ? A.a0[(p + j) * A.ld_a + row] : 0.f;
+        }
+        if (BMODE == LD_BNRELU) {
+            f32x4 z = {0, 0, 0, 0};
+            if (cok) z = *reinterpret_cast<const f32x4 *>(A.b0 + (long)col * A.Ppad + p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = (cok && p + j < s1) ? fmaxf(fmaf(z[j], bs, bt), 0.f) : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = (cok && p + j < s1) ? A.b0[(p + j) * A.ld_b + col] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
+    }
+    if (s0 >= s1) return;
+    // D: column = lane&31 (col tile), rows = 8g+4h+j
+    const int oc = 32 * tc + r;
+    if (oc < A.cols)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int orow = 32 * tr + 8 * g + 4 * h + j;
+                if (orow < A.rows) atomicAdd(&A.dW[(long)orow * A.ldw + oc], acc[4 * g + j]);
+            }
+}
+
+// ---------------------------------------------------------------- row statistics
+// grid (rows, S): two pivot-free partial sums per (row, slice) into part[(row*S+s)*2].
+//   ST_FWD     sum (z - pivot), sum (z - pivot)^2          pivot = z[row][0]
+//   ST_BWD     sum dy, sum dy*zhat                          dy = da masked by relu, zhat = (z-mean)*rstd
+//   ST_DZCLOUD sum over one cloud of dz (slice = cloud)      -> part[(cloud*rows+row)] (single value)
+enum { ST_FWD = 0, ST_BWD = 1, ST_DZCLOUD = 2 };
+struct StatArgs {
+    const float *z, *da;
+    const float *tab;    // ST_BWD: {s,t,mean,rstd}[rows]; ST_DZCLOUD: {s,t,A1,A2,A3}[rows]
+    float *part;
+    int rows, P, Ppad, S, N;
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void p2n_row_stats_kernel(StatArgs A) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, s = blockIdx.y;
+    long p0, p1;
+    if (MODE == ST_DZCLOUD) { p0 = (long)s * A.N; p1 = p0 + A.N; }
+    else {
+        const long len = ((long)A.P + A.S - 1) / A.S;
+        p0 = (long)s * len; p1 = p0 + len;
+        if (p1 > A.P) p1 = A.P;
+    }
+    const float *z = A.z + (long)row * A.Ppad;
+    const float *da = A.da ? A.da + (long)row * A.Ppad : nullptr;
+    float u = 0.f, v = 0.f;
+    if (MODE == ST_FWD) {
+        const float pivot = z[0];
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) { const float d = z[p] - pivot; u += d; v = fmaf(d, d, v); }
+    } else if (MODE == ST_BWD) {
+        const float sc = A.tab[row], sf = A.tab[A.rows + row], mean = A.tab[2 * A.rows + row], rstd = A.tab[3 * A.rows + row];
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+            const float zz = z[p];
+            const float dy = fmaf(zz, sc, sf) > 0.f ? da[p] : 0.f;
+            u += dy; v = fmaf(dy, (zz - mean) * rstd, v);
+        }
+    } else {
+        const float sc = A.tab[row], sf = A.tab[A.rows + row], a1 = A.tab[2 * A.rows + row],
+                    a2 = A.tab[3 * A.rows + row], a3 = A.tab[4 * A.rows + row];
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+            const float zz = z[p];
+            const float dy = fmaf(zz, sc, sf) > 0.f ? da[p] : 0.f;
+            u += fmaf(a3, zz, fmaf(a1, dy, a2));
+        }
+    }
+    u = block_sum_256(u, sh);
+    if (MODE != ST_DZCLOUD) v = block_sum_256(v, sh);
+    if (threadIdx.x == 0) {
+        if (MODE == ST_DZCLOUD) A.part[(long)s * A.rows + row] = u;
+        else { A.part[((long)row * A.S + s) * 2] = u; A.part[((long)row * A.S + s) * 2 + 1] = v; }
+    }
+}
+
+// forward finalize: mean, biased var -> rstd; s = gamma*rstd, t = beta - mean*s; running stats
+__global__ void p2n_bn_finalize_fwd_kernel(const float *__restrict__ part, const float *__restrict__ z, int Ppad,
+                                           int rows, int S, int P, const float *__restrict__ gamma,
+                                           const float *__restrict__ beta, float *__restrict__ run_mean,
+                                           float *__restrict__ run_var, float momentum, float *__restrict__ tab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= rows) return;
+    double u = 0, v = 0;
+    for (int s = 0; s < S; ++s) { u += part[((long)c * S + s) * 2]; v += part[((long)c * S + s) * 2 + 1]; }
+    const double pivot = z[(long)c * Ppad];
+    const double dm = u / P;
+    const double mean = pivot + dm;
+    double var = v / P - dm * dm;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + BN_EPS);
+    const double sc = (double)gamma[c] * rstd;
+    tab[c] = (float)sc;                                   // s
+    tab[rows + c] = (float)((double)beta[c] - mean * sc); // t
+    tab[2 * rows + c] = (float)mean;
+    tab[3 * rows + c] = (float)rstd;
+    if (run_mean) {
+        const double unb = P > 1 ? var * ((double)P / (P - 1)) : var;
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+    }
+}
+
+// backward finalize: dgamma, dbeta and the loader constants {s,t,A1,A2,A3}
+__global__ void p2n_bn_finalize_bwd_kernel(const float *__restrict__ part, int rows, int S, int P,
+                                           const float *__restrict__ gamma, const float *__restrict__ ftab,
+                                           float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                           float *__restrict__ btab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= rows) return;
+    double sdy = 0, sdyz = 0;
+    for (int s = 0; s < S; ++s) { sdy += part[((long)c * S + s) * 2]; sdyz += part[((long)c * S + s) * 2 + 1]; }
+    const double mean = ftab[2 * rows + c], rstd = ftab[3 * rows + c], g = gamma[c];
+    if (dgamma) dgamma[c] = (float)sdyz;
+    if (dbeta) dbeta[c] = (float)sdy;
+    const double m1 = sdy / P, m2 = sdyz / P;
+    btab[c] = ftab[c];
+    btab[rows + c] = ftab[rows + c];
+    btab[2 * rows + c] = (float)(g * rstd);                                     // A1
+    btab[3 * rows + c] = (float)(-g * rstd * m1 + g * rstd * rstd * mean * m2); // A2
+    btab[4 * rows + c] = (float)(-g * rstd * rstd * m2);                        // A3
+}
+
+// ---------------------------------------------------------------- global max branch
+// g[b][c] = max_n relu(bn(z5[c][b*N+n])), arg = lowest index attaining it
+__global__ __launch_bounds__(256) void p2n_colmax_kernel(const float *__restrict__ z, int Ppad, int N,
+                                                        const float *__restrict__ tab, int rows,
+                                                        float *__restrict__ g, int *__restrict__ arg) {
+    __shared__ unsigned long long sh[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float s = tab[c], t = tab[rows + c];
+    const float *zr = z + (long)c * Ppad + (long)b * N;
+    unsigned long long best = 0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float v = fmaxf(fmaf(zr[n], s, t), 0.f);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)n);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t2 = __shfl_xor(best, o); best = t2 > best ? t2 : best; }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) best = sh[w] > best ? sh[w] : best;
+        g[(long)b * rows + c] = __uint_as_float((unsigned)(best >> 32));
+        arg[(long)b * rows + c] = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu));
+    }
+}
+
+// out[b][r] = sum_k M[r][k] v[b][k]  (trans=0: M = W[r*ldw + col0 + k]; trans=1: M = W[k*ldw + col0 + r])
+__global__ __launch_bounds__(256) void p2n_small_gemv_kernel(const float *__restrict__ W, int ldw, int col0, int trans,
+                                                            const float *__restrict__ v, int K, int R,
+                                                            float *__restrict__ out) {
+    const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float w = trans ? W[(long)k * ldw + col0 + r] : W[(long)r * ldw + col0 + k];
+        acc = fmaf(w, v[(long)b * K + k], acc);
+    }
+    out[(long)b * R + r] = acc;
+}
+
+// dW[r][col0+k] = sum_b u[b][r] * v[b][k]
+__global__ __launch_bounds__(256) void p2n_outer_sum_kernel(const float *__restrict__ u, const float *__restrict__ v,
+                                                           int B, int R, int K, float *__restrict__ dW, int ldw,
+                                                           int col0) {
+    const int r = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(u[(long)b * R + r], v[(long)b * K + k], acc);
+    dW[(long)r * ldw + col0 + k] = acc;
+}
+
+// da5[c][b*N + arg[b][c]] += dg[b][c]   (max-pool backward: the gradient goes to the arg-max point)
+__global__ void p2n_maxpool_bwd_kernel(float *__restrict__ da, int Ppad, int N, const int *__restrict__ arg,
+                                       const float *__restrict__ dg, int rows, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * B) return;
+    const int b = i / rows, c = i % rows;
+    da[(long)c * Ppad + (long)b * N + arg[i]] += dg[i];
+}
+
+// out[e] = sum_p g[p][e]   (bias gradient of the last layer)
+__global__ __launch_bounds__(256) void p2n_colsum_pm_kernel(const float *__restrict__ g, long P, int E,
+                                                           float *__restrict__ out) {
+    __shared__ float sh[4];
+    const int e = blockIdx.x;
+    float u = 0.f;
+    for (long p = threadIdx.x; p < P; p += 256) u += g[p * E + e];
+    u = block_sum_256(u, sh);
+    if (threadIdx.x == 0) out[e] = u;
+}
+
+// ---------------------------------------------------------------- host orchestration
+namespace {
+struct Net {
+    int F, E, B, N, P, Ppad;
+    int cin[9], cout[9];
+    // pointer table in flat_order: per layer W, b, [gamma, beta, rmean, rvar]
+    const float *W[9], *b[9], *gamma[9], *beta[9];
+    float *rmean[9], *rvar[9];
+    // workspace carve
+    float *z[8];          // pre-BN conv outputs, (cout, Ppad)
+    float *ftab[8];       // {s,t,mean,rstd}[cout]
+    float *btab;          // {s,t,A1,A2,A3}[256] scratch
+    float *part;          // partial sums
+    float *wimg;          // weight image scratch (256*256)
+    float *g, *bias6c, *dzsum6, *dg;   // [B][256]
+    int *arg;
+    float *da[2];         // (256, Ppad) ping-pong
+    size_t total;
+};
+
+constexpr int STAT_S = 64;
+
+size_t carve(Net &n, char *base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    for (int l = 0; l < 8; ++l) n.z[l] = (float *)take(sizeof(float) * (size_t)n.cout[l] * n.Ppad);
+    for (int l = 0; l < 8; ++l) n.ftab[l] = (float *)take(sizeof(float) * 4 * n.cout[l]);
+    n.btab = (float *)take(sizeof(float) * 5 * 256);
+    n.part = (float *)take(sizeof(float) * 2 * 256 * STAT_S);
+    n.wimg = (float *)take(sizeof(float) * 256 * 256);
+    n.g = (float *)take(sizeof(float) * (size_t)n.B * 256);
+    n.bias6c = (float *)take(sizeof(float) * (size_t)n.B * 256);
+    n.dzsum6 = (float *)take(sizeof(float) * (size_t)n.B * 256);
+    n.dg = (float *)take(sizeof(float) * (size_t)n.B * 256);
+    n.arg = (int *)take(sizeof(int) * (size_t)n.B * 256);
+    n.da[0] = (float *)take(sizeof(float) * 256 * (size_t)n.Ppad);
+    n.da[1] = (float *)take(sizeof(float) * 256 * (size_t)n.Ppad);
+    return off;
+}
+
+void init_dims(Net &n, int B, int N, int F, int E) {
+    const int ci[9] = {F, 64, 64, 128, 128, 256, 512, 256, 128};
+    const int co[9] = {64, 64, 128, 128, 256, 256, 256, 128, E};
+    for (int l = 0; l < 9; ++l) { n.cin[l] = ci[l]; n.cout[l] = co[l]; }
+    n.F = F; n.E = E; n.B = B; n.N = N; n.P = B * N; n.Ppad = (n.P + 127) / 128 * 128;
+}
+
+void bind_params(Net &n, const void *const *ptrs) {
+    int i = 0;
+    for (int l = 0; l < 9; ++l) {
+        n.W[l] = (const float *)ptrs[i++]; n.b[l] = (const float *)ptrs[i++];
+        if (l < 8) {
+            n.gamma[l] = (const float *)ptrs[i++]; n.beta[l] = (const float *)ptrs[i++];
+            n.rmean[l] = (float *)ptrs[i++]; n.rvar[l] = (float *)ptrs[i++];
+        } else { n.gamma[l] = n.beta[l] = nullptr; n.rmean[l] = n.rvar[l] = nullptr; }
+    }
+}
+
+int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float *img, int CT, int KT, hipStream_t s) {
+    const long n = (long)CT * KT * 4 * 256;
+    hipLaunchKernelGGL(p2n_pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, col0, rows, k, trans,
+                       img, CT, KT * 4);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+int kt_for(int k) { return k <= 32 ? 1 : k <= 64 ? 2 : k <= 128 ? 4 : 8; }
+
+template <int MODE, bool PM>
+int launch_layer(const LayerArgs &a, int KT, hipStream_t s) {
+    const dim3 grid(a.Ppad / 128), blk(256);
+    const int ps = p2n_prof_begin(P2N_K_TRAIN_GEMM, s);
+    switch (KT) {
+        case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM>), grid, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM>), grid, blk, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM>), grid, blk, 0, s, a); break;
+    }
+    p2n_prof_end(ps, s);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+int wgrad_slice(int P, int tiles) {
+    // aim at ~2048 waves in flight; slices are multiples of 8 points
+    long want = 2048 / (tiles > 0 ? tiles : 1);
+    if (want < 1) want = 1;
+    long sl = (P + want - 1) / want;
+    sl = (sl + 7) / 8 * 8;
+    if (sl < 256) sl = 256;
+    return (int)sl;
+}
+
+template <int AM, int BM>
+int launch_wgrad(WgArgs a, hipStream_t s) {
+    const int ntr = (a.rows + 31) / 32;
+    a.ntc = (a.cols + 31) / 32;
+    a.slice = wgrad_slice(a.P, ntr * a.ntc);
+    const long nsl = ((long)a.P + a.slice - 1) / a.slice;
+    const int ps = p2n_prof_begin(P2N_K_TRAIN_WGRAD, s);
+    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM>), dim3((unsigned)((nsl + 3) / 4), ntr * a.ntc), dim3(256), 0, s, a);
+    p2n_prof_end(ps, s);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+}  // namespace
+
+extern "C" size_t p2n_train_workspace_bytes(int B, int N, int F, int E) {
+    if (B < 1 || N < 1 || F < 1 || E < 1) return 0;
+    Net n;
+    init_dims(n, B, N, F, E);
+    return carve(n, nullptr);
+}
+
+static int check_common(const char *fn, int B, int N, int F, int E) {
+    P2N_REQUIRE(B >= 1 && N >= 1, "%s: bad shape B=%d N=%d", fn, B, N);
+    P2N_REQUIRE((long)B * N >= 2, "%s: train-mode BatchNorm needs more than one value per channel (B*N=%ld)", fn, (long)B * N);
+    P2N_REQUIRE((long)B * N < (1L << 31) - 256, "%s: B*N too large", fn);
+    P2N_REQUIRE(F >= 1 && F <= 8, "%s: feature_dim %d not in [1,8]", fn, F);
+    P2N_REQUIRE(E >= 1 && E <= 256, "%s: embedding_dim %d not in [1,256]", fn, E);
+    return P2N_OK;
+}
+
+// Train-mode forward.  params_host: HOST array of 50 DEVICE pointers in flat order
+// (W,b,[gamma,beta,running_mean,running_var]) x layers; running stats are updated in place.
+extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, const void *const *params_host,
+                                 float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
+                                 void *workspace, size_t workspace_bytes, void *stream_) {
+    TRY(check_common("p2n_train_forward", B, N, F, E));
+    P2N_REQUIRE(x && params_host && emb, "p2n_train_forward: null pointer");
+    Net n;
+    init_dims(n, B, N, F, E);
+    const size_t need = carve(n, nullptr);
+    if (!workspace || workspace_bytes < need) {
+        p2n_set_error("p2n_train_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    P2N_REQUIRE(((uintptr_t)workspace & 255) == 0, "p2n_train_forward: workspace must be 256-byte aligned");
+    carve(n, (char *)workspace);
+    bind_params(n, params_host);
+    hipStream_t s = (hipStream_t)stream_;
+    for (int l = 0; l < 9; ++l) {
+        const int K = (l == 6) ? 256 : n.cin[l];
+        const int KT = (l == 0) ? 1 : kt_for(K);
+        const int CT = (n.cout[l] + 31) / 32;
+        TRY(pack_w(n.W[l], n.cin[l], 0, n.cout[l], K, 0, n.wimg, CT, KT, s));
+        LayerArgs a = {};
+        a.wimg = n.wimg; a.bias = n.b[l]; a.K = K; a.CT = CT; a.rows = n.cout[l];
+        a.P = n.P; a.Ppad = n.Ppad; a.N = n.N;
+        if (l == 0) { a.in0 = x; a.ld = F; a.out = n.z[0]; TRY((launch_layer<LD_X, false>(a, 1, s))); }
+        else {
+            a.in0 = n.z[l - 1]; a.tab = n.ftab[l - 1];
+            if (l == 6) a.bias_cloud = n.bias6c;
+            if (l == 8) { a.out = emb; a.ld = E; TRY((launch_layer<LD_BNRELU, true>(a, KT, s))); }
+            else { a.out = n.z[l]; TRY((launch_layer<LD_BNRELU, false>(a, KT, s))); }
+        }
+        if (l == 8) break;
+        StatArgs st = {};
+        st.z = n.z[l]; st.part = n.part; st.rows = n.cout[l]; st.P = n.P; st.Ppad = n.Ppad; st.S = STAT_S; st.N = N;
+        hipLaunchKernelGGL(p2n_row_stats_kernel<ST_FWD>, dim3(n.cout[l], STAT_S), dim3(256), 0, s, st);
+        P2N_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(p2n_bn_finalize_fwd_kernel, dim3((n.cout[l] + 63) / 64), dim3(64), 0, s, n.part, n.z[l], n.Ppad,
+                           n.cout[l], STAT_S, n.P, n.gamma[l], n.beta[l], n.rmean[l], n.rvar[l], momentum, n.ftab[l]);
+        P2N_CHECK_HIP(hipGetLastError());
+        if (l == 5) {
+            hipLaunchKernelGGL(p2n_colmax_kernel, dim3(256, B), dim3(256), 0, s, n.z[5], n.Ppad, N, n.ftab[5], 256, n.g, n.arg);
+            P2N_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(p2n_small_gemv_kernel, dim3(1, B), dim3(256), 0, s, n.W[6], 512, 256, 0, n.g, 256, 256, n.bias6c);
+            P2N_CHECK_HIP(hipGetLastError());
+            if (global_f) P2N_CHECK_HIP(hipMemcpyAsync(global_f, n.g, sizeof(float) * (size_t)B * 256, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    (void)f1; (void)f2; (void)f3;
+    return P2N_OK;
+}
+
+// Backward of p2n_train_forward (same workspace, untouched in between).  grads_host: HOST
+// array of 34 DEVICE pointers (W,b,[gamma,beta]) x layers, each fully overwritten.
+extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int N, int F, int E,
+                                  const void *const *params_host, void *const *grads_host, void *workspace,
+                                  size_t workspace_bytes, void *stream_) {
+    TRY(check_common("p2n_train_backward", B, N, F, E));
+    P2N_REQUIRE(x && gemb && params_host && grads_host, "p2n_train_backward: null pointer");
+    Net n;
+    init_dims(n, B, N, F, E);
+    const size_t need = carve(n, nullptr);
+    if (!workspace || workspace_bytes < need) {
+        p2n_set_error("p2n_train_backward: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    carve(n, (char *)workspace);
+    bind_params(n, params_host);
+    float *dW[9], *db[9], *dgam[9], *dbet[9];
+    {
+        int i = 0;
+        for (int l = 0; l < 9; ++l) {
+            dW[l] = (float *)grads_host[i++]; db[l] = (float *)grads_host[i++];
+            if (l < 8) { dgam[l] = (float *)grads_host[i++]; dbet[l] = (float *)grads_host[i++]; }
+            else dgam[l] = dbet[l] = nullptr;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    for (int l = 0; l < 9; ++l) P2N_CHECK_HIP(hipMemsetAsync(dW[l], 0, sizeof(float) * (size_t)n.cin[l] * n.cout[l], s));
+    for (int l = 0; l < 8; ++l) P2N_CHECK_HIP(hipMemsetAsync(db[l], 0, sizeof(float) * n.cout[l], s));   // sum dz = 0 under BN
+
+    // ---- layer 8 (no BN): dz8 = gemb
+    hipLaunchKernelGGL(p2n_colsum_pm_kernel, dim3(E), dim3(256), 0, s, gemb, (long)n.P, E, db[8]);
+    P2N_CHECK_HIP(hipGetLastError());
+    {
+        WgArgs w = {};
+        w.a0 = gemb; w.ld_a = E; w.b0 = n.z[7]; w.btab = n.ftab[7]; w.dW = dW[8];
+        w.rows = E; w.cols = 128; w.ldw = 128; w.P = n.P; w.Ppad = n.Ppad;
+        TRY((launch_wgrad<LD_EMBGRAD, LD_BNRELU>(w, s)));
+        const int KT = kt_for(E);
+        TRY(pack_w(n.W[8], 128, 0, 128, E, 1, n.wimg, 4, KT, s));
+        LayerArgs a = {};
+        a.in0 = gemb; a.ld = E; a.wimg = n.wimg; a.K = E; a.CT = 4; a.rows = 128;
+        a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[0];
+        TRY((launch_layer<LD_EMBGRAD, false>(a, KT, s)));
+    }
+    int cur = 0;   // n.da[cur] holds da_l for the layer being processed
+    for (int l = 7; l >= 0; --l) {
+        const int C = n.cout[l];
+        StatArgs st = {};
+        st.z = n.z[l]; st.da = n.da[cur]; st.tab = n.ftab[l]; st.part = n.part;
+        st.rows = C; st.P = n.P; st.Ppad = n.Ppad; st.S = STAT_S; st.N = N;
+        hipLaunchKernelGGL(p2n_row_stats_kernel<ST_BWD>, dim3(C, STAT_S), dim3(256), 0, s, st);
+        P2N_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(p2n_bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, s, n.part, C, STAT_S, n.P,
+                           n.gamma[l], n.ftab[l], dgam[l], dbet[l], n.btab);
+        P2N_CHECK_HIP(hipGetLastError());
+        // weight gradient
+        WgArgs w = {};
+        w.a0 = n.da[cur]; w.a1 = n.z[l]; w.atab = n.btab; w.dW = dW[l];
+        w.rows = C; w.ldw = n.cin[l]; w.P = n.P; w.Ppad = n.Ppad;
+        if (l == 0) { w.b0 = x; w.ld_b = F; w.cols = F; TRY((launch_wgrad<LD_BNBWD, LD_X>(w, s))); }
+        else {
+            w.b0 = n.z[l - 1]; w.btab = n.ftab[l - 1]; w.cols = (l == 6) ? 256 : n.cin[l];
+            TRY((launch_wgrad<LD_BNBWD, LD_BNRELU>(w, s)));
+        }
+        if (l == 6) {
+            // global branch: per-cloud sums of dz6 -> dW6[:,256:] and dg
+            StatArgs sc = st;
+            sc.tab = n.btab; sc.part = n.dzsum6;
+            hipLaunchKernelGGL(p2n_row_stats_kernel<ST_DZCLOUD>, dim3(256, B), dim3(256), 0, s, sc);
+            P2N_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(p2n_outer_sum_kernel, dim3(1, 256), dim3(256), 0, s, n.dzsum6, n.g, B, 256, 256, dW[6], 512, 256);
+            P2N_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(p2n_small_gemv_kernel, dim3(1, B), dim3(256), 0, s, n.W[6], 512, 256, 1, n.dzsum6, 256, 256, n.dg);
+            P2N_CHECK_HIP(hipGetLastError());
+        }
+        if (l == 0) break;
+        // data gradient: da_{l-1} = W_l^T . dz_l
+        const int rows = (l == 6) ? 256 : n.cin[l];
+        const int KT = kt_for(C);
+        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, rows / 32, KT, s));
+        LayerArgs a = {};
+        a.in0 = n.da[cur]; a.in1 = n.z[l]; a.tab = n.btab; a.wimg = n.wimg; a.K = C; a.CT = rows / 32; a.rows = rows;
+        a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[cur ^ 1];
+        TRY((launch_layer<LD_BNBWD, false>(a, KT, s)));
+        cur ^= 1;
+        if (l == 6) {
+            hipLaunchKernelGGL(p2n_maxpool_bwd_kernel, dim3((256 * B + 255) / 256), dim3(256), 0, s, n.da[cur], n.Ppad, N,
+                               n.arg, n.dg, 256, B);
+            P2N_CHECK_HIP(hipGetLastError());
+        }
+    }
+    return P2N_OK;
+}

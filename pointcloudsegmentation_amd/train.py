@@ -1,0 +1,106 @@
+"""Autograd bridge of the training path (libp2n_hip.so: p2n_train_forward/backward).
+
+`Point2Net` in train() mode on GPU tensors lands here (reference train.py:109,124,131:
+model.train(); embeddings = model(features); loss.backward()).  One
+torch.autograd.Function covers the whole network: the C library keeps the
+pre-BatchNorm activations in a workspace tensor owned by the autograd context and
+writes the 34 parameter gradients straight into fresh tensors.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import params as _params
+from . import runtime as _rt
+
+
+def _param_tensors(model):
+    sd = dict(model.named_parameters())
+    sd.update(dict(model.named_buffers()))
+    return [sd[k] for k in _params.flat_order()]
+
+
+def _ptr_table(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class _Point2NetTrainFn(torch.autograd.Function):
+    """forward(x, model, *learnables) -> emb; grads flow to the 34 learnable tensors."""
+
+    @staticmethod
+    def forward(ctx, x, model, momentum, update_stats, *learnables):
+        L = _lib.lib()
+        B, N, F = x.shape
+        E = model.embedding_dim
+        dev = x.device
+        tensors = _param_tensors(model)
+        for t in tensors:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("model parameters must be contiguous float32 GPU tensors")
+        if not update_stats:
+            # running statistics must not move: point the library at scratch copies
+            tensors = [t.clone() if ("running" in k) else t for k, t in zip(_params.flat_order(), tensors)]
+        nbytes = L.p2n_train_workspace_bytes(B, N, F, E)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        emb = torch.empty((B, N, E), dtype=torch.float32, device=dev)
+        table = _ptr_table(tensors)
+        with torch.cuda.device(dev):
+            _lib.check(L.p2n_train_forward(x.data_ptr(), B, N, F, E, table, float(momentum), emb.data_ptr(), None,
+                                           None, None, None, ws.data_ptr(), ws.numel(), _rt.stream_handle(dev)),
+                       "p2n_train_forward")
+        ctx.model = model
+        ctx.ws = ws
+        ctx.x = x
+        ctx.tensors = tensors     # keeps the (possibly cloned) stats alive for the backward
+        ctx.shape = (B, N, F, E)
+        return emb
+
+    @staticmethod
+    def backward(ctx, gemb):
+        L = _lib.lib()
+        B, N, F, E = ctx.shape
+        dev = gemb.device
+        gemb = gemb.contiguous()
+        order = _params.flat_order()
+        learn_keys = [k for k in order if "running" not in k]
+        sd = dict(zip(order, ctx.tensors))
+        grads = [torch.empty_like(sd[k]) for k in learn_keys]
+        with torch.cuda.device(dev):
+            _lib.check(L.p2n_train_backward(ctx.x.data_ptr(), gemb.data_ptr(), B, N, F, E, _ptr_table(ctx.tensors),
+                                            _ptr_table(grads), ctx.ws.data_ptr(), ctx.ws.numel(),
+                                            _rt.stream_handle(dev)), "p2n_train_backward")
+        ctx.ws = None
+        return (None, None, None, None) + tuple(grads)
+
+
+def forward_train(model, x):
+    """Train-mode forward of a Point2Net on a GPU tensor (B,N,F) -> (B,N,E) with autograd."""
+    if not model.training:
+        raise NotImplementedError(
+            "autograd through eval-mode BatchNorm (running statistics) is not implemented on the HIP path; "
+            "call model.train(), or wrap inference in torch.no_grad()")
+    if x.requires_grad:
+        raise NotImplementedError("the HIP training path does not produce a gradient for the input points")
+    x = _rt.require_cuda_f32(x, "x")
+    if x.size(0) * x.size(1) < 2:
+        raise ValueError("Expected more than 1 value per channel when training")   # as torch BatchNorm raises
+    order = _params.flat_order()
+    sd = dict(model.named_parameters())
+    learnables = [sd[k] for k in order if "running" not in k]
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
+    emb = _Point2NetTrainFn.apply(x, model, momentum, True, *learnables)
+    with torch.no_grad():
+        for m in bns:
+            m.num_batches_tracked += 1
+    return emb
+
+
+def encode_train(encoder, x):
+    raise NotImplementedError(
+        "PointNet2Encoder alone in train() mode on a GPU tensor is not implemented on the HIP path; "
+        "train through Point2Net")
