@@ -84,6 +84,22 @@ int p2n_train_backward(const float *x, const float *gemb, int B, int N, int feat
                        const void *const *params_host, void *const *grads_host,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* InstanceSegLoss (reference losses.py:332-373) = DiscriminativeLoss pull/push
+ * (:375-452) + SmoothnessLoss (:454-489, brute-force kNN k+1 with column 0 dropped),
+ * values AND gradient w.r.t. the embeddings in one call.
+ *   points (B,N,3), emb (B,N,E); inst (B*N): dense id of each point's (cloud,label)
+ *   pair, ids ascending in (cloud,label); cnt (T) points per id; bg (T) 1 where the
+ *   label is 0 (background, excluded); cstart (B+1) first id of each cloud.
+ *   losses (3, device) = {pull, push, smoothness}; instance = pull + push and
+ *   total = instance + 0.1*smoothness are left to the caller (losses.py:365).
+ *   demb_pull/push/smooth (B,N,E): all three or none (NULL = values only). */
+size_t p2n_instance_seg_loss_workspace_bytes(int B, int N, int embedding_dim, int T, int k);
+int p2n_instance_seg_loss(const float *points, const float *emb, const int32_t *inst, const int32_t *cnt,
+                          const int32_t *bg, const int32_t *cstart, int B, int N, int embedding_dim, int T,
+                          float delta_v, float delta_d, int k, float *losses,
+                          float *demb_pull, float *demb_push, float *demb_smooth,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- point-set operators (named by BASELINE.json north_star; the reference has
  * none of them -- SURVEY.md section 0 -- so oracle/p2n_oracle.c is their spec:
  * fp32 squared distance ((dx*dx+dy*dy)+dz*dz) without fma, lowest index wins

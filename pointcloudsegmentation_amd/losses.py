@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference loss module (reference src/models/losses.py).
+
+`InstanceSegLoss(feature_dim, delta_v, delta_d)` (reference :332-373, constructed at
+train.py:69-73) and the classes it is built from keep their names, arguments and
+returned dict keys.  GPU tensors run libp2n_hip.so (p2n_instance_seg_loss: values and
+d/d embeddings in one call); CPU tensors run a stock-PyTorch composition of the same
+formulas.  `FocalLoss` is kept because train.py:19 imports it; in the reference it
+raises on every call (BCE target (B,N,I) vs input (B,N,N)) and
+it is out of scope here, so it raises NotImplementedError with that explanation.
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from . import runtime as _rt
+
+
+def _dense_instances(labels: torch.Tensor):
+    """Integer plumbing for the HIP kernels: (B,N) labels -> dense ids per (cloud,label)
+    in ascending (cloud,label) order, counts, background flags, per-cloud id ranges."""
+    B, N = labels.shape
+    lab = labels.to(torch.int64)
+    lo = lab.min()
+    span = (lab.max() - lo + 1)
+    key = (torch.arange(B, device=lab.device).unsqueeze(1) * span + (lab - lo)).reshape(-1)
+    uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+    cloud = torch.div(uniq, span, rounding_mode="floor")
+    bg = ((uniq - cloud * span + lo) == 0)
+    cstart = torch.searchsorted(cloud, torch.arange(B + 1, device=lab.device))
+    return (inv.to(torch.int32).contiguous(), cnt.to(torch.int32).contiguous(), bg.to(torch.int32).contiguous(),
+            cstart.to(torch.int32).contiguous(), int(uniq.numel()))
+
+
+class _InstanceSegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, emb, labels, delta_v, delta_d, k):
+        L = _lib.lib()
+        points = _rt.require_cuda_f32(points, "points")
+        emb_c = _rt.require_cuda_f32(emb, "embeddings")
+        B, N, E = emb_c.shape
+        if points.shape != (B, N, 3) or labels.shape != (B, N):
+            raise ValueError(f"points {tuple(points.shape)} / embeddings {tuple(emb.shape)} / labels "
+                             f"{tuple(labels.shape)} do not agree")
+        inst, cnt, bg, cstart, T = _dense_instances(labels)
+        dev = emb_c.device
+        want = ctx.needs_input_grad[1]
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(emb_c) for _ in range(3)] if want else [None, None, None]
+        nbytes = L.p2n_instance_seg_loss_workspace_bytes(B, N, E, T, k)
+        ws = _rt.workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.p2n_instance_seg_loss(points.data_ptr(), emb_c.data_ptr(), inst.data_ptr(), cnt.data_ptr(),
+                                               bg.data_ptr(), cstart.data_ptr(), B, N, E, T, float(delta_v),
+                                               float(delta_d), int(k), losses.data_ptr(), _rt.ptr(grads[0]),
+                                               _rt.ptr(grads[1]), _rt.ptr(grads[2]), ws.data_ptr(), ws.numel(),
+                                               _rt.stream_handle(dev)), "p2n_instance_seg_loss")
+        if want:
+            ctx.save_for_backward(*grads)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        dp, dq, ds = ctx.saved_tensors
+        return None, g[0] * dp + g[1] * dq + g[2] * ds, None, None, None, None
+
+
+class DiscriminativeLoss(nn.Module):
+    """reference losses.py:375-452 (CPU tensors: stock PyTorch)."""
+
+    def __init__(self, delta_v=0.1, delta_d=0.5):
+        super().__init__()
+        self.delta_v = delta_v
+        self.delta_d = delta_d
+
+    def forward(self, embeddings: torch.Tensor, labels: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if embeddings.is_cuda:
+            raise RuntimeError("on GPU tensors use InstanceSegLoss (one fused HIP call); "
+                               "DiscriminativeLoss alone is only provided for CPU tensors")
+        B = embeddings.size(0)
+        pull = embeddings.new_zeros(())
+        push = embeddings.new_zeros(())
+        for b in range(B):
+            e, lab = embeddings[b], labels[b]
+            uniq = torch.unique(lab)
+            uniq = uniq[uniq != 0]
+            if len(uniq) == 0:
+                continue
+            means = torch.stack([e[lab == u].mean(0) for u in uniq])
+            inst_pull = embeddings.new_zeros(())
+            for i, u in enumerate(uniq):
+                dist = torch.norm(e[lab == u] - means[i].unsqueeze(0), p=2, dim=1)
+                inst_pull = inst_pull + torch.clamp(dist - self.delta_v, min=0).mean()
+            pull = pull + inst_pull / (means.size(0) + 1e-6)
+            if means.size(0) > 1:
+                nm = F.normalize(means, p=2, dim=1)
+                d = torch.cdist(nm, nm)
+                mask = torch.triu(torch.ones_like(d), diagonal=1)
+                push = push + (torch.clamp(2 * self.delta_d - d, min=0) * mask).sum() / (mask.sum() + 1e-6)
+        pull, push = pull / B, push / B
+        return {"total_loss": pull + push, "pull_loss": pull, "push_loss": push}
+
+
+class SmoothnessLoss(nn.Module):
+    """reference losses.py:454-489 (CPU tensors: stock PyTorch)."""
+
+    def __init__(self, k: int = 20):
+        super().__init__()
+        self.k = k
+
+    def forward(self, points: torch.Tensor, embeddings: torch.Tensor) -> torch.Tensor:
+        if embeddings.is_cuda:
+            raise RuntimeError("on GPU tensors use InstanceSegLoss (one fused HIP call)")
+        B = points.size(0)
+        loss = points.new_zeros(())
+        for b in range(B):
+            d = torch.cdist(points[b], points[b])
+            _, idx = d.topk(k=self.k + 1, dim=1, largest=False)
+            idx = idx[:, 1:]
+            e = embeddings[b]
+            loss = loss + torch.norm(e[idx] - e.unsqueeze(1), p=2, dim=2).mean()
+        return loss / B
+
+
+class InstanceSegLoss(nn.Module):
+    """reference losses.py:332-373: criterion(points, embeddings, labels) -> dict."""
+
+    def __init__(self, feature_dim: int = 64, delta_v: float = 0.1, delta_d: float = 0.5):
+        super().__init__()
+        self.feature_dim = feature_dim
+        self.delta_v = delta_v
+        self.delta_d = delta_d
+        self.instance_loss = DiscriminativeLoss(delta_v=delta_v, delta_d=delta_d)
+        self.smoothness_loss = SmoothnessLoss()
+
+    def forward(self, points: torch.Tensor, embeddings: torch.Tensor,
+                instance_labels: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if embeddings.is_cuda:
+            k = self.smoothness_loss.k
+            if points.size(1) < k + 1:
+                raise RuntimeError(f"selected index k out of range: {k + 1} neighbours from {points.size(1)} points")
+            L = _InstanceSegLossFn.apply(points, embeddings, instance_labels, self.delta_v, self.delta_d, k)
+            pull, push, smooth = L[0], L[1], L[2]
+            inst = pull + push
+            return {"total_loss": inst + 0.1 * smooth, "instance_loss": inst, "smoothness_loss": smooth,
+                    "pull_loss": pull, "push_loss": push}
+        en = F.normalize(embeddings, p=2, dim=2)
+        inst = self.instance_loss(en, instance_labels)
+        smooth = self.smoothness_loss(points, en)
+        return {"total_loss": inst["total_loss"] + 0.1 * smooth, "instance_loss": inst["total_loss"],
+                "smoothness_loss": smooth, "pull_loss": inst["pull_loss"], "push_loss": inst["push_loss"]}
+
+
+class FocalLoss(nn.Module):
+    """Name kept for `from src.models.losses import InstanceSegLoss, FocalLoss`
+    (reference train.py:19).  The reference's implementation (:492-543) raises on every
+    call and train.py calls it with the wrong arity (train.py:127); it is out of scope."""
+
+    def __init__(self, alpha: float = 0.25, gamma: float = 2.0):
+        super().__init__()
+        self.alpha = alpha
+        self.gamma = gamma
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("FocalLoss is broken in the reference (shape mismatch in BCE) and is not ported; "
+                                  "use loss.type: instance_seg")
