@@ -10,7 +10,7 @@
 #define P2N_PTS_PER_WAVE 32          // one 32-column MFMA block of points per wave
 #define P2N_WAVES_PER_WG 4
 #define P2N_PTS_PER_WG (P2N_PTS_PER_WAVE * P2N_WAVES_PER_WG)
-#define P2N_RING 8                   // weight fragments kept in flight per wave
+#define P2N_CHUNK 32                 // weight fragments per LDS chunk (32 KiB); two chunks are resident
 #define P2N_FRAG_FLOATS 256          // one fragment = 64 lanes x 4 floats = 1 KiB
 #define P2N_TAB_MAX 1792             // encoder scale/shift tables: 2*(64+64+128+128+256+256)
 
@@ -26,10 +26,10 @@ struct P2nLayout {
     long raw_w[P2N_NLAYER], raw_b[P2N_NLAYER], raw_g[P2N_NLAYER], raw_beta[P2N_NLAYER],
         raw_mean[P2N_NLAYER], raw_var[P2N_NLAYER];
     long raw_total;
-    long enc_stream;        // layers 0..5, fragment order, then P2N_RING zero fragments
+    long enc_stream;        // layers 0..5 in consumption order [layer][ct][k-group]
     long enc_frags;
-    long head_stream;       // (layer 6 tile, layer 7 k-slice) x 8, then layer 8, then zero fragments
-    long head_frags;
+    long head_stream;       // layers 6 and 7 as [kt][ct][g], layer 8 as [ct][kt][g]
+    long head_frags;        // both streams are zero-padded to a chunk multiple plus one spare chunk
     long scale[P2N_NLAYER], shift[P2N_NLAYER];
     long w6g;               // (256,256) row-major: the global-feature half of layer 6
     long total;
@@ -61,10 +61,10 @@ static inline P2nLayout p2n_make_layout(int F, int E) {
     L.enc_stream = o;
     L.enc_frags = 0;
     for (int l = 0; l < 6; ++l) L.enc_frags += (long)(L.cpad[l] / 32) * (L.kpad[l] / 8);
-    o += (L.enc_frags + P2N_RING) * P2N_FRAG_FLOATS;
+    o += ((L.enc_frags + P2N_CHUNK - 1) / P2N_CHUNK + 1) * P2N_CHUNK * P2N_FRAG_FLOATS;
     L.head_stream = o;
-    L.head_frags = 8L * (32 + 16) + (long)(L.cpad[8] / 32) * 16;
-    o += (L.head_frags + P2N_RING) * P2N_FRAG_FLOATS;
+    L.head_frags = 256 + 128 + (long)(L.cpad[8] / 32) * 16;
+    o += ((L.head_frags + P2N_CHUNK - 1) / P2N_CHUNK + 1) * P2N_CHUNK * P2N_FRAG_FLOATS;
     for (int l = 0; l < P2N_NLAYER; ++l) { L.scale[l] = o; o += L.cpad[l]; L.shift[l] = o; o += L.cpad[l]; }
     L.w6g = o; o += 256L * 256;
     L.total = o;

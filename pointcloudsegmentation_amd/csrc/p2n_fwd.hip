@@ -7,7 +7,7 @@
 //                       (W6[:,256:] . g replaces the concat of reference
 //                       point2net.py:78-79)
 //   p2n_head_kernel     head layers 6..8 (reference point2net.py:57-65,82) and
-//                       the (B,E,N)->(B,N,E) transpose of :85 as a coalesced store
+//                       the (B,E,N)->(B,N,E) transpose of :85 folded into the store
 //
 // Design: one wave owns 32 points (one 32-column block of v_mfma_f32_32x32x2_f32)
 // and carries their activations through every layer IN REGISTERS.  With D = W.X
@@ -17,12 +17,19 @@
 // (k = 32*kt + 8*g + 4*h + j  <->  register 4g+j of tile kt, lane half h), and the
 // permutation is absorbed into the weight image at pack time.  So activations never
 // touch LDS or HBM between layers; the only HBM traffic is x in, the f3 spill across
-// the global-max dependency, and emb out.  Weights stream from L2 as 1-KiB
-// lane-linear fragments (one global_load_dwordx4 per 4 MFMAs per wave) through a
-// register ring P2N_RING fragments deep.  fp32 in, fp32 accumulate: exact-f32 MFMA.
+// the global-max dependency, and emb out.
+//
+// Weights: the packed image is a linear stream of 1-KiB lane-linear fragments in the
+// exact order the kernel consumes them, cut into 32-fragment chunks.  A workgroup
+// (4 waves, 128 points) keeps two chunks in LDS: while every wave computes on chunk c
+// (one ds_read_b128 per 4 MFMAs), the chunk after it lands by LDS-DMA
+// (global_load_lds_dwordx4, 8 fragments per wave, no staging registers); one
+// __syncthreads() per chunk (8192 MFMA cycles per wave) retires the DMA and frees the
+// other buffer.  fp32 in, fp32 accumulate: exact-f32 MFMA.
 #include "p2n_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define CHUNK_FLOATS (P2N_CHUNK * P2N_FRAG_FLOATS)   // 8192 floats = 32 KiB
 
 // ------------------------------------------------------------------ pack
 __global__ void p2n_pack_kernel(const float *__restrict__ raw, float *__restrict__ packed, P2nLayout L) {
@@ -66,18 +73,30 @@ __global__ void p2n_pack_kernel(const float *__restrict__ raw, float *__restrict
             if (f < L.enc_frags) {
                 for (int ll = 0; ll < 6; ++ll) {
                     long nf = (long)(L.cpad[ll] / 32) * (L.kpad[ll] / 8);
-                    if (f < nf) { l = ll; ct = (int)(f / (L.kpad[ll] / 8)); G = (int)(f % (L.kpad[ll] / 8)); break; }
+                    if (f < nf) {
+                        l = ll;
+                        const int CT = L.cpad[ll] / 32;
+                        if (ll == 0) { ct = (int)f; G = 0; }                      // K = 8: one fragment per tile
+                        else if (ll < 5) {                                       // [kt][ct][g]
+                            ct = (int)((f >> 2) % CT); G = (int)(4 * (f / (4 * CT)) + (f & 3));
+                        } else {                                                 // [half][kt][ct%4][g]
+                            const long r2 = f & 127;
+                            ct = (int)(4 * (f >> 7) + ((r2 >> 2) & 3)); G = (int)(4 * (r2 >> 4) + (r2 & 3));
+                        }
+                        break;
+                    }
                     f -= nf;
                 }
             }
         } else if (f < L.head_frags) {
-            if (f < 8 * 48) {
-                int ct6 = (int)(f / 48), q = (int)(f % 48);
-                if (q < 32) { l = 6; ct = ct6; G = q; }
-                else { l = 7; ct = (q - 32) / 4; G = 4 * ct6 + ((q - 32) & 3); }
-            } else {
-                long q = f - 8 * 48;
-                l = 8; ct = (int)(q / 16); G = (int)(q % 16);
+            if (f < 256) {            // layer 6: [kt][ct][g]
+                l = 6; ct = (int)((f >> 2) & 7); G = (int)(4 * (f >> 5) + (f & 3));
+            } else if (f < 384) {     // layer 7: [kt][ct][g]
+                long q = f - 256;
+                l = 7; ct = (int)((q >> 2) & 3); G = (int)(4 * (q >> 4) + (q & 3));
+            } else {                  // layer 8: [ct][kt][g]
+                long q = f - 384;
+                l = 8; ct = (int)(q >> 4); G = (int)(q & 15);
             }
         }
         if (l >= 0) {
@@ -90,11 +109,39 @@ __global__ void p2n_pack_kernel(const float *__restrict__ raw, float *__restrict
 }
 
 // ------------------------------------------------------------------ helpers
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// This wave's quarter (8 fragments) of chunk c of a weight stream -> LDS buffer c&1.
+// LDS-DMA: the destination is wave-uniform base + lane*16, i.e. the lane-linear fragment image.
+__device__ __forceinline__ void stage_chunk(const float *__restrict__ stream, float *wbuf, int c, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < P2N_CHUNK / P2N_WAVES_PER_WG; ++i) {
+        const int f = wave * (P2N_CHUNK / P2N_WAVES_PER_WG) + i;
+        __builtin_amdgcn_global_load_lds((gbl_void *)(stream + ((long)c * P2N_CHUNK + f) * P2N_FRAG_FLOATS + lane * 4),
+                                         (lds_void *)(wbuf + (c & 1) * CHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16, 0, 0);
+    }
+}
+
+// Entering fragment f of the stream: at a chunk boundary wait for the chunk (vmcnt(0) +
+// barrier inside __syncthreads), which also proves every wave left the other buffer,
+// then start the DMA of the next chunk into that other buffer.
+__device__ __forceinline__ void chunk_gate(int f, const float *__restrict__ stream, float *wbuf, int wave, int lane) {
+    if (f % P2N_CHUNK == 0) {
+        __syncthreads();
+        stage_chunk(stream, wbuf, f / P2N_CHUNK + 1, wave, lane);
+    }
+}
+
+__device__ __forceinline__ f32x4 lds_frag(const float *wbuf, int f, int lane) {
+    return *reinterpret_cast<const f32x4 *>(wbuf + ((f / P2N_CHUNK) & 1) * CHUNK_FLOATS +
+                                            (f % P2N_CHUNK) * P2N_FRAG_FLOATS + lane * 4);
+}
+
 // y = relu(acc*scale + shift) on one 32x32 accumulator tile; channel of register
 // 4g+j in lane half h is 32*ct + 8g + 4h + j.
 template <bool RELU>
-__device__ __forceinline__ f32x16 epilogue(const f32x16 acc, const float *__restrict__ scale,
-                                           const float *__restrict__ shift, int ct, int h) {
+__device__ __forceinline__ f32x16 epilogue(const f32x16 acc, const float *scale, const float *shift, int ct, int h) {
     f32x16 out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -109,44 +156,47 @@ __device__ __forceinline__ f32x16 epilogue(const f32x16 acc, const float *__rest
     return out;
 }
 
-// One pointwise layer on a wave's 32 points.  Consumes CT*KT*4 consecutive weight
-// fragments starting at stream index F0 (compile-time, so ring slots are static).
-template <int KT, int CT, int F0, typename Sink>
-__device__ __forceinline__ void layer_stream(const f32x4 *__restrict__ wl, f32x4 (&ring)[P2N_RING],
-                                             const f32x16 (&in)[KT], Sink &&sink) {
+// One pointwise layer on a wave's 32 points, k-tile outer: CT independent accumulators
+// take turns on the matrix pipe (no MFMA ever waits on its predecessor) and every epilogue
+// of the layer happens once, after the last k-tile.  Consumes KT*CT*4 consecutive weight
+// fragments, ordered [kt][ct][g], starting at stream index F0 (compile-time, so LDS
+// offsets are immediates).  acc must come in zeroed.
+template <int KT, int CT, int F0>
+__device__ __forceinline__ void layer_kt_outer(const float *__restrict__ stream, float *wbuf, int wave, int lane,
+                                               const f32x16 (&in)[KT], f32x16 (&acc)[CT]) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        f32x16 acc;
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int f = F0 + (ct * KT + kt) * 4 + g;
-                const f32x4 a = ring[f % P2N_RING];
-                ring[f % P2N_RING] = wl[(long)(f + P2N_RING) * P2N_WAVE];
+                const int f = F0 + (kt * CT + ct) * 4 + g;
+                chunk_gate(f, stream, wbuf, wave, lane);
+                const f32x4 a = lds_frag(wbuf, f, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], in[kt][4 * g + j], acc);
+                for (int j = 0; j < 4; ++j) acc[ct] = MFMA32(a[j], in[kt][4 * g + j], acc[ct]);
             }
-        }
-        sink(ct, acc);
-    }
 }
 
-// max over the 32 lanes that share a lane half; result valid in lanes 16..31 and 48..63
-__device__ __forceinline__ float half_wave_max(float v) {
-    int t;
-    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    v = fmaxf(v, __int_as_float(t));
-    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    v = fmaxf(v, __int_as_float(t));
-    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);  // row_half_mirror
-    v = fmaxf(v, __int_as_float(t));
-    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true);  // row_mirror
-    v = fmaxf(v, __int_as_float(t));
-    t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1,3
-    v = fmaxf(v, __int_as_float(t));
+template <int CT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&t)[CT]) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[c][i] = 0.f;
+}
+
+// max over the 16 lanes of a DPP row, on the bit patterns of non-negative floats
+__device__ __forceinline__ unsigned row_max_u32(unsigned v) {
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+    v = v > t ? v : t;
     return v;
 }
 
@@ -173,27 +223,26 @@ __device__ __forceinline__ void store_feat(float *__restrict__ f, const f32x16 v
         for (int j = 0; j < 4; ++j) f[((long)b * C + 32 * ct + 8 * g + 4 * h + j) * N + n] = v[4 * g + j];
 }
 
+#define ENC_LDS_FLOATS (2 * CHUNK_FLOATS + 256 + P2N_TAB_MAX)
+
 template <bool FEATS>
-__global__ __launch_bounds__(256) void p2n_encoder_kernel(EncArgs A) {
-    // one LDS array: [4][256] wave maxima, then the scale/shift tables (epilogues read
-    // them with ds_read so they never wait on the global weight stream's vmcnt)
-    __shared__ __attribute__((aligned(16))) float lds[P2N_WAVES_PER_WG * 256 + P2N_TAB_MAX];
-    float (*smax)[256] = reinterpret_cast<float (*)[256]>(lds);
-    float *tab = lds + P2N_WAVES_PER_WG * 256;
+__global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
+    // one LDS array: two weight chunks, [256] channel maxima, scale/shift tables
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *wbuf = lds;
+    unsigned *smax = reinterpret_cast<unsigned *>(lds + 2 * CHUNK_FLOATS);
+    float *tab = lds + 2 * CHUNK_FLOATS + 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / A.tiles, tile = blockIdx.x % A.tiles;
     const long n = ((long)tile * P2N_WAVES_PER_WG + wave) * P2N_PTS_PER_WAVE + p;
-    for (int i = threadIdx.x; i < A.tab_n; i += 256) tab[i] = A.packed[A.tab + i];
-    __syncthreads();
+    const float *pk = A.packed;
+    const float *stream = pk + A.stream;
+    stage_chunk(stream, wbuf, 0, wave, lane);
+    for (int i = threadIdx.x; i < A.tab_n; i += 256) tab[i] = pk[A.tab + i];
+    smax[threadIdx.x] = 0u;
     const bool valid = n < A.N;
     const long grp = (long)blockIdx.x * P2N_WAVES_PER_WG + wave;
-
-    const float *pk = A.packed;
-    const f32x4 *wl = reinterpret_cast<const f32x4 *>(pk + A.stream) + lane;
-    f32x4 ring[P2N_RING];
-#pragma unroll
-    for (int i = 0; i < P2N_RING; ++i) ring[i] = wl[(long)i * P2N_WAVE];
 
     // layer 0 operand: x[n][4h+j], zero beyond F (K padded to 8) and beyond the cloud
     f32x4 xin;
@@ -209,57 +258,72 @@ __global__ __launch_bounds__(256) void p2n_encoder_kernel(EncArgs A) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const f32x4 a = ring[ct % P2N_RING];
-        ring[ct % P2N_RING] = wl[(long)(ct + P2N_RING) * P2N_WAVE];
+        chunk_gate(ct, stream, wbuf, wave, lane);   // ct == 0: first barrier (chunk 0, tables, smax)
+        const f32x4 a = lds_frag(wbuf, ct, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], xin[j], acc);
         a0[ct] = epilogue<true>(acc, tab + A.scale[0], tab + A.shift[0], ct, h);
     }
-    // stream positions: L0 2 frags, L1 16, L2 32, L3 64, L4 128, L5 256
+    // stream positions: L0 2 frags, L1 16, L2 32, L3 64, L4 128, L5 2 x 128
     f32x16 a1[2];
-    layer_stream<2, 2, 2>(wl, ring, a0, [&](int ct, const f32x16 acc) {
-        a1[ct] = epilogue<true>(acc, tab + A.scale[1], tab + A.shift[1], ct, h);
+    zero_tiles(a1);
+    layer_kt_outer<2, 2, 2>(stream, wbuf, wave, lane, a0, a1);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        a1[ct] = epilogue<true>(a1[ct], tab + A.scale[1], tab + A.shift[1], ct, h);
         if (FEATS) if (A.f1) store_feat<64>(A.f1, a1[ct], b, ct, h, n, A.N);
-    });
+    }
     f32x16 a2[4];
-    layer_stream<2, 4, 18>(wl, ring, a1, [&](int ct, const f32x16 acc) {
-        a2[ct] = epilogue<true>(acc, tab + A.scale[2], tab + A.shift[2], ct, h);
-    });
+    zero_tiles(a2);
+    layer_kt_outer<2, 4, 18>(stream, wbuf, wave, lane, a1, a2);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) a2[ct] = epilogue<true>(a2[ct], tab + A.scale[2], tab + A.shift[2], ct, h);
     f32x16 a3[4];
-    layer_stream<4, 4, 50>(wl, ring, a2, [&](int ct, const f32x16 acc) {
-        a3[ct] = epilogue<true>(acc, tab + A.scale[3], tab + A.shift[3], ct, h);
+    zero_tiles(a3);
+    layer_kt_outer<4, 4, 50>(stream, wbuf, wave, lane, a2, a3);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        a3[ct] = epilogue<true>(a3[ct], tab + A.scale[3], tab + A.shift[3], ct, h);
         if (FEATS) if (A.f2) store_feat<128>(A.f2, a3[ct], b, ct, h, n, A.N);
-    });
+    }
     f32x16 a4[8];
-    layer_stream<4, 8, 114>(wl, ring, a3, [&](int ct, const f32x16 acc) {
-        a4[ct] = epilogue<true>(acc, tab + A.scale[4], tab + A.shift[4], ct, h);
-    });
+    zero_tiles(a4);
+    layer_kt_outer<4, 8, 114>(stream, wbuf, wave, lane, a3, a4);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) a4[ct] = epilogue<true>(a4[ct], tab + A.scale[4], tab + A.shift[4], ct, h);
+    // layer 5 in two halves of four output tiles (the 8 x 16 accumulators of a full k-outer
+    // pass would not fit beside its 128 input registers); results leave through the spill
     float *sp = A.spill + grp * (256L * P2N_PTS_PER_WAVE) + lane * 4;
-    layer_stream<8, 8, 242>(wl, ring, a4, [&](int ct, const f32x16 acc) {
-        f32x16 v = epilogue<true>(acc, tab + A.scale[5], tab + A.shift[5], ct, h);
-        if (FEATS) if (A.f3) store_feat<256>(A.f3, v, b, ct, h, n, A.N);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-            *reinterpret_cast<f32x4 *>(sp + (ct * 4 + g) * P2N_FRAG_FLOATS) = o;
-        }
-        // post-ReLU values are >= 0, so 0 is the neutral element for masked points
+    for (int half = 0; half < 2; ++half) {
+        f32x16 a5[4];
+        zero_tiles(a5);
+        if (half == 0) layer_kt_outer<8, 4, 242>(stream, wbuf, wave, lane, a4, a5);
+        else layer_kt_outer<8, 4, 370>(stream, wbuf, wave, lane, a4, a5);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = half_wave_max(valid ? v[i] : 0.f);
-        if (p == 16) {
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int ct = 4 * half + c4;
+            const f32x16 v = epilogue<true>(a5[c4], tab + A.scale[5], tab + A.shift[5], ct, h);
+            if (FEATS) if (A.f3) store_feat<256>(A.f3, v, b, ct, h, n, A.N);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(&smax[wave][32 * ct + 8 * g + 4 * h]) = o;
+                *reinterpret_cast<f32x4 *>(sp + (ct * 4 + g) * P2N_FRAG_FLOATS) = o;
             }
+            // channel max over the workgroup's points: post-ReLU values are >= 0, so their bit
+            // patterns order as unsigned integers and 0 is the neutral element for masked
+            // points.  DPP max inside each 16-lane row, then one LDS atomic per row.
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned m = row_max_u32(valid ? __float_as_uint(v[4 * g + j]) : 0u);
+                    if ((lane & 15) == 0) atomicMax(&smax[32 * ct + 8 * g + 4 * h + j], m);
+                }
         }
-    });
-    __syncthreads();
-    {
-        const int c = threadIdx.x;
-        float m = fmaxf(fmaxf(smax[0][c], smax[1][c]), fmaxf(smax[2][c], smax[3][c]));
-        A.partial[(long)blockIdx.x * 256 + c] = m;
     }
+    __syncthreads();
+    A.partial[(long)blockIdx.x * 256 + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ mid
@@ -271,21 +335,35 @@ __global__ __launch_bounds__(256) void p2n_mid_kernel(const float *__restrict__ 
                                                       float *__restrict__ global_f) {
     __shared__ __attribute__((aligned(16))) float g[256];
     const int b = blockIdx.x, t = threadIdx.x;
-    float m = 0.f;
-    for (int i = 0; i < tiles; ++i) m = fmaxf(m, partial[((long)b * tiles + i) * 256 + t]);
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    const float *pp = partial + (long)b * tiles * 256 + t;
+    int i = 0;
+    for (; i + 3 < tiles; i += 4) {
+        m0 = fmaxf(m0, pp[(long)i * 256]);
+        m1 = fmaxf(m1, pp[(long)(i + 1) * 256]);
+        m2 = fmaxf(m2, pp[(long)(i + 2) * 256]);
+        m3 = fmaxf(m3, pp[(long)(i + 3) * 256]);
+    }
+    for (; i < tiles; ++i) m0 = fmaxf(m0, pp[(long)i * 256]);
+    const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     g[t] = m;
     if (blockIdx.y == 0 && global_f) global_f[(long)b * 256 + t] = m;
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
     const f32x4 gv = *reinterpret_cast<const f32x4 *>(&g[4 * lane]);
+    float s[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int co = blockIdx.y * 32 + wave * 8 + i;
+    for (int q = 0; q < 8; ++q) {
+        const int co = blockIdx.y * 32 + wave * 8 + q;
         const f32x4 w = *reinterpret_cast<const f32x4 *>(packed + w6g + (long)co * 256 + 4 * lane);
-        float s = (w[0] * gv[0] + w[1] * gv[1]) + (w[2] * gv[2] + w[3] * gv[3]);
+        s[q] = (w[0] * gv[0] + w[1] * gv[1]) + (w[2] * gv[2] + w[3] * gv[3]);
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) shift6c[(long)b * 256 + co] = fmaf(s, packed[scale6 + co], packed[shift6 + co]);
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o);
+        const int co = blockIdx.y * 32 + wave * 8 + q;
+        if (lane == 0) shift6c[(long)b * 256 + co] = fmaf(s[q], packed[scale6 + co], packed[shift6 + co]);
     }
 }
 
@@ -302,124 +380,131 @@ struct HeadArgs {
     int scale6, scale7, shift7, scale8, shift8;   // offsets inside the table
 };
 
-__global__ __launch_bounds__(256) void p2n_head_kernel(HeadArgs A) {
+__global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
+    // LDS carve: two weight chunks, [tab_n] scale/shift tables, [256] this cloud's layer-6 shift
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wbuf = smem;
+    float *tab = smem + 2 * CHUNK_FLOATS;
+    float *sh6 = tab + A.tab_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / A.tiles, tile = blockIdx.x % A.tiles;
     const long n0 = ((long)tile * P2N_WAVES_PER_WG + wave) * P2N_PTS_PER_WAVE;
     const long grp = (long)blockIdx.x * P2N_WAVES_PER_WG + wave;
     const float *pk = A.packed;
-    // LDS carve: [tab_n] scale/shift tables, [256] this cloud's layer-6 shift, then the
-    // four per-wave output tiles
-    float *tab = smem;
-    float *sh6 = smem + A.tab_n;
+    const float *stream = pk + A.stream;
+    stage_chunk(stream, wbuf, 0, wave, lane);
     for (int i = threadIdx.x; i < A.tab_n; i += 256) tab[i] = pk[A.tab + i];
     sh6[threadIdx.x] = A.shift6c[(long)b * 256 + threadIdx.x];
-    __syncthreads();
-    const f32x4 *wl = reinterpret_cast<const f32x4 *>(pk + A.stream) + lane;
-    f32x4 ring[P2N_RING];
-#pragma unroll
-    for (int i = 0; i < P2N_RING; ++i) ring[i] = wl[(long)i * P2N_WAVE];
 
-    f32x16 f3in[8];
-    {
-        const f32x4 *sp = reinterpret_cast<const f32x4 *>(A.spill + grp * (256L * P2N_PTS_PER_WAVE)) + lane;
+    // ---- layer 6, k-tile outer: the f3 tile of k-slice kt is loaded once (next one
+    // prefetched), used by all eight output tiles, dropped.  Chunk kt of the stream holds
+    // exactly the 32 fragments of k-slice kt.
+    const f32x4 *sp = reinterpret_cast<const f32x4 *>(A.spill + grp * (256L * P2N_PTS_PER_WAVE)) + lane;
+    f32x16 acc6[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc6[c][i] = 0.f;
+    f32x4 cur[4], nxt[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cur[g] = sp[g * P2N_WAVE];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        if (kt < 7) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nxt[g] = sp[((kt + 1) * 4 + g) * P2N_WAVE];
+        }
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = sp[(ct * 4 + g) * P2N_WAVE];
+                const int f = kt * 32 + ct * 4 + g;
+                chunk_gate(f, stream, wbuf, wave, lane);
+                const f32x4 a = lds_frag(wbuf, f, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) f3in[ct][4 * g + j] = v[j];
+                for (int j = 0; j < 4; ++j) acc6[ct] = MFMA32(a[j], cur[g][j], acc6[ct]);
             }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cur[g] = nxt[g];
     }
-    f32x16 acc7[4];
+    f32x16 a6[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a6[c] = epilogue<true>(acc6[c], tab + A.scale6, sh6, c, h);
+
+    // ---- layer 7, k-tile outer as well: a6[kt] dies as soon as its slice is consumed
+    f32x16 a7[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc7[c][i] = 0.f;
+        for (int i = 0; i < 16; ++i) a7[c][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 256 + kt * 16 + ct * 4 + g;
+                chunk_gate(f, stream, wbuf, wave, lane);
+                const f32x4 a = lds_frag(wbuf, f, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a7[ct] = MFMA32(a[j], a6[kt][4 * g + j], a7[ct]);
+            }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a7[c] = epilogue<true>(a7[c], tab + A.scale7, tab + A.shift7, c, h);
 
-    // layer 6 tile ct6 (32 frags) feeds, as k-slice ct6, the four layer-7 tiles (16 frags)
-#pragma unroll
-    for (int ct6 = 0; ct6 < 8; ++ct6) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = ct6 * 48 + kt * 4 + g;
-                const f32x4 a = ring[f % P2N_RING];
-                ring[f % P2N_RING] = wl[(long)(f + P2N_RING) * P2N_WAVE];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], f3in[kt][4 * g + j], acc);
-            }
-        const f32x16 a6 = epilogue<true>(acc, tab + A.scale6, sh6, ct6, h);
-#pragma unroll
-        for (int ct7 = 0; ct7 < 4; ++ct7)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = ct6 * 48 + 32 + ct7 * 4 + g;
-                const f32x4 a = ring[f % P2N_RING];
-                ring[f % P2N_RING] = wl[(long)(f + P2N_RING) * P2N_WAVE];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc7[ct7] = MFMA32(a[j], a6[4 * g + j], acc7[ct7]);
-            }
-    }
-    f32x16 a7[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a7[c] = epilogue<true>(acc7[c], tab + A.scale7, tab + A.shift7, c, h);
-
-    // layer 8: runtime number of 32-channel tiles, results staged in LDS as [point][channel]
-    const int rs = A.ct8 * 32 + 4;   // padded row stride (floats): conflict-free b128 writes
-    float *tilebuf = smem + A.tab_n + 256 + (long)wave * 32 * rs;
-    const f32x4 *wl8 = wl + 384L * P2N_WAVE;
-#pragma unroll 1
-    for (int ct8 = 0; ct8 < A.ct8; ++ct8) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = kt * 4 + g;   // 384 % RING == 0 and 16 % RING == 0: slots stay static
-                const f32x4 a = ring[f % P2N_RING];
-                ring[f % P2N_RING] = wl8[(long)(f + P2N_RING) * P2N_WAVE];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], a7[kt][4 * g + j], acc);
-            }
-        const f32x16 v = epilogue<false>(acc, tab + A.scale8, tab + A.shift8, ct8, h);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-            *reinterpret_cast<f32x4 *>(&tilebuf[p * rs + 32 * ct8 + 8 * g + 4 * h]) = o;
-        }
-        wl8 += 16L * P2N_WAVE;
-    }
-    __syncthreads();
-    // the wave's 32 points x E floats are one contiguous block of emb
+    // ---- layer 8: runtime number of 32-channel tiles, two per chunk (16 fragments each).
+    // Output: lane (p,h) holds 4 consecutive channels per register group, so every point's
+    // row is written as 16-byte pieces that together fill whole 128-byte lines of emb (B,N,E).
     const int E = A.E;
-    long rows = (long)A.N - n0;
-    if (rows > 32) rows = 32;
-    if (rows <= 0) return;
-    float *dst = A.emb + ((long)b * A.N + n0) * E;
-    if ((E & 3) == 0) {
-        const int cpr = E >> 2;
-        const int total = (int)rows * cpr;
-        for (int c = lane; c < total; c += 64) {
-            const int row = c / cpr, col = c - row * cpr;
-            *reinterpret_cast<f32x4 *>(dst + (long)c * 4) = *reinterpret_cast<const f32x4 *>(&tilebuf[row * rs + col * 4]);
-        }
-    } else {
-        const int total = (int)rows * E;
-        for (int c = lane; c < total; c += 64) {
-            const int row = c / E, col = c - row * E;
-            dst[c] = tilebuf[row * rs + col];
+    const long n = n0 + p;
+    const bool valid = n < A.N;
+    float *dst = A.emb + ((long)b * A.N + n) * E;
+    const bool vec = (E & 3) == 0;
+    const int nch8 = (A.ct8 + 1) / 2;
+#pragma unroll 1
+    for (int c8 = 0; c8 < nch8; ++c8) {
+        const int c = 12 + c8;
+        __syncthreads();
+        stage_chunk(stream, wbuf, c + 1, wave, lane);
+        const float *wb = wbuf + (c & 1) * CHUNK_FLOATS + lane * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int ct8 = 2 * c8 + half;
+            if (ct8 < A.ct8) {
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(wb + (half * 16 + kt * 4 + g) * P2N_FRAG_FLOATS);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], a7[kt][4 * g + j], acc);
+                    }
+                const f32x16 v = epilogue<false>(acc, tab + A.scale8, tab + A.shift8, ct8, h);
+                if (valid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int e0 = 32 * ct8 + 8 * g + 4 * h;
+                        if (vec) {
+                            if (e0 < E) {
+                                f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                                *reinterpret_cast<f32x4 *>(dst + e0) = o;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (e0 + j < E) dst[e0 + j] = v[4 * g + j];
+                        }
+                    }
+                }
+            }
         }
     }
+    // drain the spare chunk's DMA before the workgroup's LDS is released
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -454,6 +539,14 @@ extern "C" size_t p2n_forward_eval_workspace_bytes(int B, int N, int F, int E) {
     return sizeof(float) * (tiles * P2N_WAVES_PER_WG * 256 * P2N_PTS_PER_WAVE + tiles * 256 + (size_t)B * 256);
 }
 
+template <typename K>
+static int allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return P2N_OK;
+}
+
 extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, const float *packed, float *emb,
                                 float *global_f, float *f1, float *f2, float *f3, void *workspace,
                                 size_t workspace_bytes, void *stream_) {
@@ -486,11 +579,17 @@ extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, cons
     ea.N = N; ea.F = F; ea.tiles = tiles; ea.stream = L.enc_stream;
     ea.tab = L.scale[0]; ea.tab_n = (int)(L.scale[6] - L.scale[0]);
     for (int l = 0; l < 6; ++l) { ea.scale[l] = (int)(L.scale[l] - L.scale[0]); ea.shift[l] = (int)(L.shift[l] - L.scale[0]); }
+    const size_t enc_lds = sizeof(float) * ENC_LDS_FLOATS;
     int ps = p2n_prof_begin(P2N_K_ENCODER, stream);
-    if (f1 || f2 || f3)
-        hipLaunchKernelGGL(p2n_encoder_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, stream, ea);
-    else
-        hipLaunchKernelGGL(p2n_encoder_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, stream, ea);
+    if (f1 || f2 || f3) {
+        int rc = allow_big_lds(p2n_encoder_kernel<true>, enc_lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(p2n_encoder_kernel<true>, dim3((unsigned)ntiles), dim3(256), enc_lds, stream, ea);
+    } else {
+        int rc = allow_big_lds(p2n_encoder_kernel<false>, enc_lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(p2n_encoder_kernel<false>, dim3((unsigned)ntiles), dim3(256), enc_lds, stream, ea);
+    }
     p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
     ps = p2n_prof_begin(P2N_K_MID, stream);
@@ -507,10 +606,10 @@ extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, cons
     ha.tab = L.scale[6]; ha.tab_n = (int)(L.w6g - L.scale[6]);
     ha.scale6 = 0; ha.scale7 = (int)(L.scale[7] - L.scale[6]); ha.shift7 = (int)(L.shift[7] - L.scale[6]);
     ha.scale8 = (int)(L.scale[8] - L.scale[6]); ha.shift8 = (int)(L.shift[8] - L.scale[6]);
-    const size_t lds = sizeof(float) * ((size_t)ha.tab_n + 256 + P2N_WAVES_PER_WG * 32 * (size_t)(L.cpad[8] + 4));
-    if (lds > 64 * 1024) {
-        P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_head_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = sizeof(float) * (2 * (size_t)CHUNK_FLOATS + ha.tab_n + 256);
+    {
+        int rc = allow_big_lds(p2n_head_kernel, lds);
+        if (rc) return rc;
     }
     ps = p2n_prof_begin(P2N_K_HEAD, stream);
     hipLaunchKernelGGL(p2n_head_kernel, dim3((unsigned)ntiles), dim3(256), lds, stream, ha);
