@@ -79,9 +79,9 @@ __global__ void p2n_pack_kernel(const float *__restrict__ raw, float *__restrict
                         if (ll == 0) { ct = (int)f; G = 0; }                      // K = 8: one fragment per tile
                         else if (ll < 5) {                                       // [kt][ct][g]
                             ct = (int)((f >> 2) % CT); G = (int)(4 * (f / (4 * CT)) + (f & 3));
-                        } else {                                                 // [half][kt][ct%4][g]
-                            const long r2 = f & 127;
-                            ct = (int)(4 * (f >> 7) + ((r2 >> 2) & 3)); G = (int)(4 * (r2 >> 4) + (r2 & 3));
+                        } else {                                                 // [quarter][kt][ct%2][g]
+                            const long r2 = f & 63;
+                            ct = (int)(2 * (f >> 6) + ((r2 >> 2) & 1)); G = (int)(4 * (r2 >> 3) + (r2 & 3));
                         }
                         break;
                     }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
         for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], xin[j], acc);
         a0[ct] = epilogue<true>(acc, tab + A.scale[0], tab + A.shift[0], ct, h);
     }
-    // stream positions: L0 2 frags, L1 16, L2 32, L3 64, L4 128, L5 2 x 128
+    // stream positions: L0 2 frags, L1 16, L2 32, L3 64, L4 128, L5 4 x 64
     f32x16 a1[2];
     zero_tiles(a1);
     layer_kt_outer<2, 2, 2>(stream, wbuf, wave, lane, a0, a1);
@@ -291,19 +291,22 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
     layer_kt_outer<4, 8, 114>(stream, wbuf, wave, lane, a3, a4);
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) a4[ct] = epilogue<true>(a4[ct], tab + A.scale[4], tab + A.shift[4], ct, h);
-    // layer 5 in two halves of four output tiles (the 8 x 16 accumulators of a full k-outer
-    // pass would not fit beside its 128 input registers); results leave through the spill
+    // layer 5 in four passes of two output tiles: with its 128 input registers live, two
+    // independent accumulators (32 registers) leave room for the epilogue without spilling;
+    // results leave through the spill and the channel max
     float *sp = A.spill + grp * (256L * P2N_PTS_PER_WAVE) + lane * 4;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        f32x16 a5[4];
+    for (int q = 0; q < 4; ++q) {
+        f32x16 a5[2];
         zero_tiles(a5);
-        if (half == 0) layer_kt_outer<8, 4, 242>(stream, wbuf, wave, lane, a4, a5);
-        else layer_kt_outer<8, 4, 370>(stream, wbuf, wave, lane, a4, a5);
+        if (q == 0) layer_kt_outer<8, 2, 242>(stream, wbuf, wave, lane, a4, a5);
+        else if (q == 1) layer_kt_outer<8, 2, 306>(stream, wbuf, wave, lane, a4, a5);
+        else if (q == 2) layer_kt_outer<8, 2, 370>(stream, wbuf, wave, lane, a4, a5);
+        else layer_kt_outer<8, 2, 434>(stream, wbuf, wave, lane, a4, a5);
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            const int ct = 4 * half + c4;
-            const f32x16 v = epilogue<true>(a5[c4], tab + A.scale[5], tab + A.shift[5], ct, h);
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ct = 2 * q + c2;
+            const f32x16 v = epilogue<true>(a5[c2], tab + A.scale[5], tab + A.shift[5], ct, h);
             if (FEATS) if (A.f3) store_feat<256>(A.f3, v, b, ct, h, n, A.N);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
