@@ -6,6 +6,7 @@
 // oracle/p2n_oracle.c: fp32 squared distance ((dx*dx + dy*dy) + dz*dz) with separate
 // multiply and add, lowest index wins ties.  All kernels below evaluate exactly that
 // expression (explicit __fmul_rn/__fadd_rn), so indices are bit-exact by construction.
+#include <stdlib.h>
 #include "p2n_common.h"
 
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -38,6 +39,30 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
         v = t > v ? t : v;
     }
     return v;
+}
+
+// DPP reductions on 32-bit unsigned values: one VALU instruction per step, no LDS.
+#define DPP_MAX_STEP(v, ctrl, rmask, keep)                                                            \
+    do {                                                                                              \
+        const unsigned t_ = (unsigned)__builtin_amdgcn_update_dpp((keep) ? (int)(v) : 0, (int)(v), (ctrl), (rmask), 0xF, !(keep)); \
+        (v) = (v) > t_ ? (v) : t_;                                                                    \
+    } while (0)
+
+// max over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+    DPP_MAX_STEP(v, 0xB1, 0xF, false);    // quad_perm [1,0,3,2]
+    DPP_MAX_STEP(v, 0x4E, 0xF, false);    // quad_perm [2,3,0,1]
+    DPP_MAX_STEP(v, 0x141, 0xF, false);   // row_half_mirror
+    DPP_MAX_STEP(v, 0x140, 0xF, false);   // row_mirror
+    return v;
+}
+
+// max over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = row16_max_u32(v);
+    DPP_MAX_STEP(v, 0x142, 0xA, true);    // row_bcast15 into rows 1,3
+    DPP_MAX_STEP(v, 0x143, 0xC, true);    // row_bcast31 into rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 struct FpsArgs {
@@ -104,23 +129,23 @@ __global__ __launch_bounds__(FPS_THREADS) void p2n_fps_kernel(FpsArgs A) {
             by = take ? py[s] : by;
             bz = take ? pz[s] : bz;
         }
-        const u64 key = ((u64)__float_as_uint(best) << 32) | binv;
-        const u64 wmax = wave_max_u64(key);
+        // wave argmax on the 64-bit key (distance bits, inverted index) as two 32-bit DPP maxima
+        const unsigned hi = __float_as_uint(best);
+        const unsigned whi = wave_max_u32(hi);
+        const unsigned wlo = wave_max_u32(hi == whi ? binv : 0u);
         const int buf = it & 1;
-        if (key == wmax) {   // keys are unique within a cloud: exactly one lane
-            wkey[buf][wave] = wmax;
+        if (hi == whi && binv == wlo) {   // keys are unique within a cloud: exactly one lane
+            wkey[buf][wave] = ((u64)whi << 32) | wlo;
             wxyz[buf][wave][0] = bx; wxyz[buf][wave][1] = by; wxyz[buf][wave][2] = bz;
         }
         __syncthreads();
-        // workgroup argmax: 16 wave keys, one per lane, reduced inside every wave
+        // workgroup argmax: the 16 wave keys sit one per lane in every 16-lane row
         const u64 mine = wkey[buf][lane & (FPS_WAVES - 1)];
-        u64 k = mine;
-#pragma unroll
-        for (int o = 1; o < FPS_WAVES; o <<= 1) {
-            const u64 o2 = __shfl_xor(k, o);
-            k = o2 > k ? o2 : k;
-        }
-        const int kw = __builtin_ctzll(__ballot(mine == k)) & (FPS_WAVES - 1);
+        const unsigned mhi = (unsigned)(mine >> 32), mlo = (unsigned)mine;
+        const unsigned khi = row16_max_u32(mhi);
+        const unsigned klo = row16_max_u32(mhi == khi ? mlo : 0u);
+        const u64 k = ((u64)khi << 32) | klo;
+        const int kw = __builtin_ctzll(__ballot(mhi == khi && mlo == klo)) & (FPS_WAVES - 1);
         if (A.G == 1) {
             cur = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));
             cx = wxyz[buf][kw][0]; cy = wxyz[buf][kw][1]; cz = wxyz[buf][kw][2];
@@ -155,6 +180,10 @@ __global__ __launch_bounds__(FPS_THREADS) void p2n_fps_kernel(FpsArgs A) {
 }
 
 static int fps_pick_g(int B, int N) {
+    if (const char *e = getenv("P2N_FPS_G")) {   // tuning override (tools/fps_sweep.py)
+        const int g = atoi(e);
+        if (g >= 1 && g <= 64 && (long)g * FPS_THREADS * FPS_MAX_PPT >= N && (long)g * B <= 256) return g;
+    }
     // one workgroup holds up to FPS_MAX_PPT points per thread; prefer ~8 per thread when the
     // chip has spare CUs, but all B*G workgroups must be co-resident (<= 256)
     const int cap = FPS_THREADS * FPS_MAX_PPT;
