@@ -141,6 +141,21 @@ int p2n_three_interpolate(const float *feat, const int32_t *idx, const float *we
 int p2n_three_interpolate_bwd(const float *grad_out, const int32_t *idx, const float *weight,
                               int B, int C, int m, int n, float *grad_feat, void *stream);
 
+/* ---- set-abstraction / feature-propagation building blocks (no reference counterpart:
+ * the north star names hierarchical levels, the reference has none; parity unpinned).
+ * Shared MLP layer = Conv(k=1) + folded BatchNorm(eval) + optional ReLU over any
+ * flattened trailing extent L: in (B,Cin,L), W (Cout,Cin), scale/shift (Cout) ->
+ * out (B,Cout,L) = act(scale*(W.in)+shift).  Group max-pool: (B,C,M,ns) -> (B,C,M). */
+/* Fused SA grouping: xyz (B,N,3), new_xyz (B,M,3), feat (B,C,N) or NULL with C=0,
+ * idx (B,M,ns) -> out (B,3+C,M,ns) = [xyz[idx]-new_xyz ; feat[idx]]. */
+int p2n_sa_group(const float *xyz, const float *new_xyz, const float *feat, const int32_t *idx,
+                 int B, int C, int N, int M, int ns, float *out, void *stream);
+size_t p2n_pointwise_layer_workspace_bytes(int Cin, int Cout);
+int p2n_pointwise_layer(const float *in, int B, int Cin, long L, const float *W, const float *scale,
+                        const float *shift, int relu, int Cout, float *out,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int p2n_group_max(const float *in, int B, int C, int M, int ns, float *out, void *stream);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * While enabled, every kernel launch is bracketed by HIP events on its stream.
  * p2n_profile_collect synchronises and fills, per kernel id (0 encoder, 1 mid,

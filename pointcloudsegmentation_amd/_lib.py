@@ -51,6 +51,10 @@ SIGNATURES = {
     "p2n_instance_seg_loss_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "p2n_instance_seg_loss": (c_int, [c_f, c_f, c_i, c_i, c_i, c_i, c_int, c_int, c_int, c_int, c_float, c_float,
                                       c_int, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    "p2n_sa_group": (c_int, [c_f, c_f, c_f, c_i, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]),
+    "p2n_pointwise_layer_workspace_bytes": (c_sz, [c_int, c_int]),
+    "p2n_pointwise_layer": (c_int, [c_f, c_int, c_int, ctypes.c_long, c_f, c_f, c_f, c_int, c_int, c_f, c_vp, c_sz, c_vp]),
+    "p2n_group_max": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_vp]),
     "p2n_profile_enable": (c_int, [c_int]),
     "p2n_profile_collect": (c_int, [c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
 }

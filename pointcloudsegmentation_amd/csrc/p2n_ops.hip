@@ -466,6 +466,46 @@ __global__ __launch_bounds__(256) void p2n_group_gather_bwd_kernel(const float *
         if (c0 + c < C) atomicAdd(&gfeat[((long)b * C + c0 + c) * N + i], gout[((long)b * C + c0 + c) * MS + j]);
 }
 
+// Set-abstraction grouping, fused: out (B, 3+C, M, ns) = [ xyz[idx] - new_xyz ; feat[idx] ]
+// (relative coordinates of every group member followed by its features).
+__global__ __launch_bounds__(256) void p2n_sa_group_kernel(const float *__restrict__ xyz,
+                                                          const float *__restrict__ new_xyz,
+                                                          const float *__restrict__ feat,
+                                                          const int32_t *__restrict__ idx, int C, int N, int M, int ns,
+                                                          float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long MS = (long)M * ns;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= MS) return;
+    const int i = clamp_idx(idx[(long)b * MS + j], N);
+    const int CC = C + 3;
+    if (blockIdx.y == 0) {
+        const int m = (int)(j / ns);
+        const float *q = xyz + ((long)b * N + i) * 3;
+        const float *c = new_xyz + ((long)b * M + m) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) out[((long)b * CC + a) * MS + j] = __fsub_rn(q[a], c[a]);
+    } else {
+        const int c0 = (blockIdx.y - 1) * GG_CH;
+#pragma unroll
+        for (int c = 0; c < GG_CH; ++c)
+            if (c0 + c < C) out[((long)b * CC + 3 + c0 + c) * MS + j] = feat[((long)b * C + c0 + c) * N + i];
+    }
+}
+
+extern "C" int p2n_sa_group(const float *xyz, const float *new_xyz, const float *feat, const int32_t *idx, int B, int C,
+                            int N, int M, int ns, float *out, void *stream) {
+    P2N_REQUIRE(B >= 0 && C >= 0 && N >= 1 && M >= 0 && ns >= 1, "p2n_sa_group: bad shape");
+    if (B == 0 || M == 0) return P2N_OK;
+    P2N_REQUIRE(xyz && new_xyz && idx && out && (feat || C == 0), "p2n_sa_group: null pointer");
+    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH + 1 <= 65535, "p2n_sa_group: B or C too large");
+    const long MS = (long)M * ns;
+    hipLaunchKernelGGL(p2n_sa_group_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH + 1, B), dim3(256), 0,
+                       (hipStream_t)stream, xyz, new_xyz, feat, idx, C, N, M, ns, out);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
 extern "C" int p2n_group_gather(const float *feat, const int32_t *idx, int B, int C, int N, int M, int ns, float *out,
                                 void *stream) {
     P2N_REQUIRE(B >= 0 && C >= 0 && N >= 1 && M >= 0 && ns >= 0, "p2n_group_gather: bad shape");
