@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void p2n_smooth_fwd_kernel(const float *__rest
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
-// smoothness backward w.r.t. en: den[q] += w*(en_q - en_p)/d, den[p] -= same (atomics; den zeroed before)
+// smoothness backward w.r.t. en: den[q] += w*(en_q - en_p)/d (atomics: q is a neighbour of many
+// points), den[p] -= the sum of the same terms (accumulated in registers, one atomic per element)
 __global__ __launch_bounds__(256) void p2n_smooth_bwd_kernel(const float *__restrict__ en, const int *__restrict__ idx,
                                                             long P, int N, int E, int k1, float w,
                                                             float *__restrict__ den) {
@@ -255,21 +256,32 @@ __global__ __launch_bounds__(256) void p2n_smooth_bwd_kernel(const float *__rest
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
     const long base = (p / N) * (long)N;
+    float self[4] = {0.f, 0.f, 0.f, 0.f};   // E <= 256: up to 4 channels per lane
+    float ep[4];
+    {
+        int c4 = 0;
+        for (int c = lane; c < E; c += 64, ++c4) ep[c4] = en[p * E + c];
+    }
     for (int j = 1; j < k1; ++j) {
         const long q = base + idx[p * k1 + j];
+        float dq[4];
         float s = 0.f;
-        for (int c = lane; c < E; c += 64) { const float d = en[q * E + c] - en[p * E + c]; s = fmaf(d, d, s); }
+        int c4 = 0;
+        for (int c = lane; c < E; c += 64, ++c4) { dq[c4] = en[q * E + c] - ep[c4]; s = fmaf(dq[c4], dq[c4], s); }
         s = wave_sum(s);
         const float d = sqrtf(s);
         if (d > 0.f) {
             const float r = w / d;
-            for (int c = lane; c < E; c += 64) {
-                const float g = (en[q * E + c] - en[p * E + c]) * r;
+            c4 = 0;
+            for (int c = lane; c < E; c += 64, ++c4) {
+                const float g = dq[c4] * r;
                 atomicAdd(&den[q * E + c], g);
-                atomicAdd(&den[p * E + c], -g);
+                self[c4] -= g;
             }
         }
     }
+    int c4 = 0;
+    for (int c = lane; c < E; c += 64, ++c4) atomicAdd(&den[p * E + c], self[c4]);
 }
 
 // out[0..2] = {pull, push, smooth}: deterministic final sums

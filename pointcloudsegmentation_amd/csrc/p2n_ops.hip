@@ -333,9 +333,8 @@ extern "C" int p2n_ball_query(const float *xyz, const float *new_xyz, int B, int
 #define KNN_TILE 4096   // reference points per LDS tile (48 KiB)
 
 __device__ __forceinline__ float dpp_wave_shr1(float v, float fill) {
-    // lane l <- lane l-1; lane 0 <- fill
-    const float up = __shfl_up(v, 1);
-    return (threadIdx.x & 63) == 0 ? fill : up;
+    // lane l <- lane l-1 across the whole wave (DPP wave_shr:1, one VALU op); lane 0 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
 
 __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__restrict__ query,
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__
             while (mask) {
                 const int src = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const float cd = __shfl(d, src);
+                const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
                 if (!(cd < kth)) continue;          // the k-th best tightened since the ballot
                 const int ci = t0 + i0 + src;
                 const bool gt = ld > cd;            // this lane's entry moves one rank down
@@ -383,7 +382,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__
                 const bool pgt = pd > cd;
                 ld = gt ? (pgt ? pd : cd) : ld;
                 li = gt ? (pgt ? pi : ci) : li;
-                kth = __shfl(ld, k - 1);
+                kth = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld), k - 1));
             }
         }
     }

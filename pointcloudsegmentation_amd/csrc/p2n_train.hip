@@ -161,67 +161,101 @@ struct WgArgs {
     const float *b0;    // B side: LD_BNRELU: z_prev (cols,Ppad); LD_X: x (P,F)
     const float *btab;  // {s,t}[cols]
     float *dW;          // (rows, ldw) row-major, accumulated with atomics (zeroed by the caller)
-    int rows, cols, ldw, P, Ppad, ld_a, ld_b, slice, ntc;   // ntc = column tiles
+    int rows, cols, ldw, P, Ppad, ld_a, ld_b, slice, ntc;   // ntc = 64-wide column blocks
 };
+
+// Workgroup = 4 waves = a 64 x 64 block of dW (2 x 2 MFMA tiles) over one slice of points.
+// Per step of 64 points the workgroup loads both operand blocks ONCE with row-contiguous
+// 64-byte pieces, applies the fused transforms (BatchNorm/ReLU backward on the A side,
+// BatchNorm+ReLU forward on the B side) once per element, and parks them in LDS as
+// [row][point] with a 4-float pad (conflict-free ds_read_b128); every wave then feeds its
+// tile's 32 MFMAs from LDS.
+#define WG_TILE 64
+#define WG_PTS 64
+#define WG_LD (WG_PTS + 4)
+
+template <int MODE>
+__device__ __forceinline__ void wgrad_load_block(float *__restrict__ dst, const float *__restrict__ s0,
+                                                 const float *__restrict__ s1, const float *__restrict__ tab,
+                                                 int row0, int nrows, int ntab, long p0, long pend, int Ppad, int ld) {
+    const int t = threadIdx.x;
+    if (MODE == LD_BNBWD || MODE == LD_BNRELU) {
+        const int r = t >> 2, seg = (t & 3) * 16;
+        const int row = row0 + r;
+        const bool rok = row < nrows;
+        float c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+        if (rok) {
+            c0 = tab[row]; c1 = tab[ntab + row];
+            if (MODE == LD_BNBWD) { c2 = tab[2 * ntab + row]; c3 = tab[3 * ntab + row]; c4 = tab[4 * ntab + row]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long p = p0 + seg + 4 * i;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (rok && p < pend) {   // slices start at multiples of 64 and Ppad is a multiple of 128: in-row loads
+                const f32x4 z = *reinterpret_cast<const f32x4 *>((MODE == LD_BNBWD ? s1 : s0) + (long)row * Ppad + p);
+                if (MODE == LD_BNBWD) {
+                    const f32x4 da = *reinterpret_cast<const f32x4 *>(s0 + (long)row * Ppad + p);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dy = fmaf(z[j], c0, c1) > 0.f ? da[j] : 0.f;
+                        o[j] = (p + j < pend) ? fmaf(c4, z[j], fmaf(c2, dy, c3)) : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (p + j < pend) ? fmaxf(fmaf(z[j], c0, c1), 0.f) : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4 *>(dst + r * WG_LD + seg + 4 * i) = o;
+        }
+    } else {   // point-major sources: gemb (P,E) or x (P,F)
+        const int r = t & 63, seg = (t >> 6) * 16;
+        const int row = row0 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long p = p0 + seg + i;
+            dst[r * WG_LD + seg + i] = (row < nrows && p < pend) ? s0[p * ld + row] : 0.f;
+        }
+    }
+}
 
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void p2n_wgrad_kernel(WgArgs A) {
+    __shared__ __attribute__((aligned(16))) float sa[WG_TILE * WG_LD], sb[WG_TILE * WG_LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int tr = blockIdx.y / A.ntc, tc = blockIdx.y % A.ntc;
-    const long s0 = ((long)blockIdx.x * 4 + wave) * A.slice;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int br = blockIdx.y / A.ntc, bc = blockIdx.y % A.ntc;
+    const long s0 = (long)blockIdx.x * A.slice;
     long s1 = s0 + A.slice;
     if (s1 > A.P) s1 = A.P;
-    const int row = 32 * tr + r, col = 32 * tc + r;
-    const bool rok = row < A.rows, cok = col < A.cols;
-    float as = 0, at = 0, a1 = 0, a2 = 0, a3 = 0, bs = 0, bt = 0;
-    if (AMODE == LD_BNBWD && rok) {
-        as = A.atab[row]; at = A.atab[A.rows + row]; a1 = A.atab[2 * A.rows + row];
-        a2 = A.atab[3 * A.rows + row]; a3 = A.atab[4 * A.rows + row];
-    }
-    if (BMODE == LD_BNRELU && cok) { bs = A.btab[col]; bt = A.btab[A.cols + col]; }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (long p0 = s0; p0 < s1; p0 += 8) {
-        const long p = p0 + 4 * h;
-        float av[4], bv[4];
-        if (AMODE == LD_BNBWD) {
-            f32x4 da = {0, 0, 0, 0}, z = {0, 0, 0, 0};
-            if (rok) {   // slice starts are multiples of 8 and Ppad of 128: the 16-byte loads stay in the row
-                da = *reinterpret_cast<const f32x4 *>(A.a0 + (long)row * A.Ppad + p);
-                z = *reinterpret_cast<const f32x4 *>(A.a1 + (long)row * A.Ppad + p);
-            }
+    for (long p0 = s0; p0 < s1; p0 += WG_PTS) {
+        __syncthreads();
+        wgrad_load_block<AMODE>(sa, A.a0, A.a1, A.atab, br * WG_TILE, A.rows, A.rows, p0, s1, A.Ppad, A.ld_a);
+        wgrad_load_block<BMODE>(sb, A.b0, nullptr, A.btab, bc * WG_TILE, A.cols, A.cols, p0, s1, A.Ppad, A.ld_b);
+        __syncthreads();
+        const float *pa = sa + (32 * wr + r) * WG_LD + 4 * h;
+        const float *pb = sb + (32 * wc + r) * WG_LD + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dy = fmaf(z[j], as, at) > 0.f ? da[j] : 0.f;
-                av[j] = (rok && p + j < s1) ? fmaf(a3, z[j], fmaf(a1, dy, a2)) : 0.f;
-            }
-        } else {
+        for (int G = 0; G < WG_PTS / 8; ++G) {
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(pa + 8 * G);
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(pb + 8 * G);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) av[j] = (rok && p + j < s1) ? A.a0[(p + j) * A.ld_a + row] : 0.f;
+            for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
         }
-        if (BMODE == LD_BNRELU) {
-            f32x4 z = {0, 0, 0, 0};
-            if (cok) z = *reinterpret_cast<const f32x4 *>(A.b0 + (long)col * A.Ppad + p);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = (cok && p + j < s1) ? fmaxf(fmaf(z[j], bs, bt), 0.f) : 0.f;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = (cok && p + j < s1) ? A.b0[(p + j) * A.ld_b + col] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
     }
     if (s0 >= s1) return;
-    // D: column = lane&31 (col tile), rows = 8g+4h+j
-    const int oc = 32 * tc + r;
+    // D: column = lane&31 (input channel), rows = 8g+4h+j (output channel)
+    const int oc = bc * WG_TILE + 32 * wc + r;
     if (oc < A.cols)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int orow = 32 * tr + 8 * g + 4 * h + j;
+                const int orow = br * WG_TILE + 32 * wr + 8 * g + 4 * h + j;
                 if (orow < A.rows) atomicAdd(&A.dW[(long)orow * A.ldw + oc], acc[4 * g + j]);
             }
 }
@@ -490,24 +524,24 @@ int launch_layer(const LayerArgs &a, int KT, hipStream_t s) {
     return P2N_OK;
 }
 
-int wgrad_slice(int P, int tiles) {
-    // aim at ~2048 waves in flight; slices are multiples of 8 points
-    long want = 2048 / (tiles > 0 ? tiles : 1);
+int wgrad_slice(int P, int blocks) {
+    // aim at ~1024 workgroups in flight; slices are multiples of 64 points
+    long want = 1024 / (blocks > 0 ? blocks : 1);
     if (want < 1) want = 1;
     long sl = (P + want - 1) / want;
-    sl = (sl + 7) / 8 * 8;
-    if (sl < 256) sl = 256;
+    sl = (sl + 63) / 64 * 64;
+    if (sl < 512) sl = 512;
     return (int)sl;
 }
 
 template <int AM, int BM>
 int launch_wgrad(WgArgs a, hipStream_t s) {
-    const int ntr = (a.rows + 31) / 32;
-    a.ntc = (a.cols + 31) / 32;
+    const int ntr = (a.rows + 63) / 64;
+    a.ntc = (a.cols + 63) / 64;
     a.slice = wgrad_slice(a.P, ntr * a.ntc);
     const long nsl = ((long)a.P + a.slice - 1) / a.slice;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_WGRAD, s);
-    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM>), dim3((unsigned)((nsl + 3) / 4), ntr * a.ntc), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM>), dim3((unsigned)nsl, ntr * a.ntc), dim3(256), 0, s, a);
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
