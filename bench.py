@@ -113,6 +113,16 @@ def fps_leg(device):
             "status": ops.fps_status(device)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of this workload's kernel, from the committed PMC summary (counters
+    cannot be read from inside the process); None when the file is absent."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["bytes_per_launch"].get(kernel)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,9 +200,11 @@ def main():
             "kernels_ms": {k: v[0] for k, v in kernels.items() if v[1]},
             "roofline": {"bound": "mfma", "kernel": f"p2n_{dom}_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None,
+                         "traffic": pmc_traffic(dom),
                          "note": f"{FLOP_PER_PT[dom]} algorithmic FLOP/pt x {pts_step} pts per launch / "
-                                 f"{dom_ms:.4f} ms mean launch (HIP events on the launch stream, {kernels[dom][1]} launches)"},
+                                 f"{dom_ms:.4f} ms mean launch (HIP events on the launch stream, {kernels[dom][1]} launches); "
+                                 "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes "
+                                 "(profiles/pmc_traffic.json), not collected live"},
         }
         if world == 1:
             if not args.no_fps:

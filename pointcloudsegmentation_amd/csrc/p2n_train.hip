@@ -53,14 +53,32 @@ struct LayerArgs {
     int K, CT, rows, P, Ppad, N, ld;   // ld: F for LD_X, E for LD_EMBGRAD / OUT_PM
 };
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+#define TL_CHUNK_FLOATS (32 * 256)   // 32 fragments = 32 KiB
+
+// this wave's 8 fragments of weight chunk c -> LDS buffer c&1 (LDS-DMA, lane-linear image)
+__device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *wbuf, int c, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = wave * 8 + i;
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(wimg + ((long)c * 32 + f) * 256 + lane * 4),
+                                         (lds_void_t *)(wbuf + (c & 1) * TL_CHUNK_FLOATS + f * 256), 16, 0, 0);
+    }
+}
+
 template <int MODE, int KT, bool OUT_PM>
-__global__ __launch_bounds__(256) void p2n_train_layer_kernel(LayerArgs A) {
+__global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
+    // weights: two 32-fragment chunks in LDS, the next one landing by LDS-DMA while this one is
+    // consumed (same scheme as p2n_fwd.hip); a chunk holds 32/(4*KT) output tiles
+    __shared__ __attribute__((aligned(16))) float wbuf[2 * TL_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float tab[5 * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const long pg = ((long)blockIdx.x * 4 + wave) * 32 + p;
     const bool valid = pg < A.P;
     constexpr int KP = KT * 32;   // padded reduction length
+    tl_stage(A.wimg, wbuf, 0, wave, lane);   // first weight chunk flies while the operands load
     if (MODE == LD_BNRELU || MODE == LD_BNBWD) {
         const int nt = (MODE == LD_BNRELU ? 2 : 5);
         for (int i = threadIdx.x; i < nt * KP; i += 256) {
@@ -112,9 +130,14 @@ __global__ __launch_bounds__(256) void p2n_train_layer_kernel(LayerArgs A) {
             }
         }
     const int cloud = valid ? (int)(pg / A.N) : 0;
-    const f32x4 *wl = reinterpret_cast<const f32x4 *>(A.wimg) + lane;
+    constexpr int TPC = 32 / (4 * KT);   // output tiles per weight chunk
 #pragma unroll 1
     for (int ct = 0; ct < A.CT; ++ct) {
+        if (ct % TPC == 0) {
+            __syncthreads();   // chunk ct/TPC has landed (vmcnt(0) + barrier); the other buffer is free
+            tl_stage(A.wimg, wbuf, ct / TPC + 1, wave, lane);
+        }
+        const float *wb = wbuf + ((ct / TPC) & 1) * TL_CHUNK_FLOATS + (ct % TPC) * (KT * 4 * 256) + lane * 4;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -122,7 +145,7 @@ __global__ __launch_bounds__(256) void p2n_train_layer_kernel(LayerArgs A) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 a = wl[(long)((ct * KT + kt) * 4 + g) * 64];
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(wb + (kt * 4 + g) * 256);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], in[kt][4 * g + j], acc);
             }
@@ -151,6 +174,7 @@ __global__ __launch_bounds__(256) void p2n_train_layer_kernel(LayerArgs A) {
             }
         }
     }
+    __syncthreads();   // the spare chunk's DMA must land before the workgroup's LDS is released
 }
 
 // ---------------------------------------------------------------- wgrad: dW = dz . a^T over points
@@ -470,7 +494,7 @@ size_t carve(Net &n, char *base) {
     for (int l = 0; l < 8; ++l) n.ftab[l] = (float *)take(sizeof(float) * 4 * n.cout[l]);
     n.btab = (float *)take(sizeof(float) * 5 * 256);
     n.part = (float *)take(sizeof(float) * 2 * 256 * STAT_S);
-    n.wimg = (float *)take(sizeof(float) * 256 * 256);
+    n.wimg = (float *)take(sizeof(float) * (256 * 256 + 2 * 32 * 256));   // + spare chunks the prefetch may touch
     n.g = (float *)take(sizeof(float) * (size_t)n.B * 256);
     n.bias6c = (float *)take(sizeof(float) * (size_t)n.B * 256);
     n.dzsum6 = (float *)take(sizeof(float) * (size_t)n.B * 256);
