@@ -63,7 +63,8 @@ def test_golden_other_embedding_dim():
     assert_close_to_max(emb.cpu().numpy(), g["emb"], TOL, "emb E=32")
 
 
-@pytest.mark.parametrize("B,N", [(1, 31), (1, 32), (1, 33), (2, 127), (2, 128), (2, 129), (5, 640), (1, 40000)])
+@pytest.mark.parametrize("B,N", [(1, 31), (1, 32), (1, 33), (2, 127), (2, 128), (2, 129), (5, 640), (1, 40000),
+                                 (1, 150000), (1, 166499)])   # BASELINE configs[2] / configs[0] full scenes
 def test_vs_oracle_ragged_sizes(model, ref_params, B, N):
     from oracle import oracle
     from pointcloudsegmentation_amd.synth import make_batch
