@@ -144,3 +144,31 @@ def three_interpolate(feat, idx, w):
     if rc:
         raise ValueError("orc_three_interpolate: index out of range")
     return out
+
+
+def normalize_rows(emb):
+    """reference inference.py:124 in numpy's float32 evaluation order."""
+    emb = _c32(emb)
+    out = np.empty_like(emb)
+    rc = lib().orc_normalize_rows(_fp(emb), ctypes.c_long(emb.shape[0]), emb.shape[1], _fp(out))
+    if rc:
+        raise ValueError(f"orc_normalize_rows rc={rc}")
+    return out
+
+
+def dbscan(x_normalised, eps=0.1, min_samples=50, return_counts=False):
+    """scikit-learn DBSCAN semantics on already-normalised rows; labels 0 = noise, 1.. clusters
+    (reference inference.py:127-140)."""
+    x = _c32(x_normalised)
+    n, d = x.shape
+    labels = np.empty(n, np.int32)
+    counts = np.empty(n, np.int32)
+    rc = lib().orc_dbscan(_fp(x), ctypes.c_long(n), d, ctypes.c_double(eps), int(min_samples), _ip(labels), _ip(counts))
+    if rc:
+        raise ValueError(f"orc_dbscan rc={rc}")
+    return (labels, counts) if return_counts else labels
+
+
+def cluster_embeddings(emb, eps=0.1, min_samples=50):
+    """reference inference.py:106-142 end to end."""
+    return dbscan(normalize_rows(emb), eps, min_samples)

@@ -305,3 +305,136 @@ int orc_three_interpolate(const float *feat, const int32_t *idx, const float *w,
         }
     return 0;
 }
+
+/* ===========================================================================
+ * Embedding clustering: restates reference
+ * inference.py:106-142 (cluster_embeddings) = row L2-normalisation (:124) +
+ * scikit-learn DBSCAN(eps, min_samples).fit_predict (:127-128; scikit-learn is a
+ * requirements.txt dependency, ">=1.2.2", 1.7.2 in the build container) + relabel
+ * noise -> 0, cluster k -> k+1 (:131-140).
+ *
+ * DBSCAN as scikit-learn defines it (sklearn/cluster/_dbscan.py, _dbscan_inner.pyx):
+ *   neighbourhood(i) = { j : ||x_i - x_j|| <= eps }  (self included; brute force for D > 15,
+ *                      squared distances compared with eps*eps in float64);
+ *   core(i)          = |neighbourhood(i)| >= min_samples;
+ *   clusters         = connected components of the core points, numbered in ascending order
+ *                      of their lowest core index (the scan `for i in range(n)` opens a new
+ *                      cluster at the first unlabelled core point and expands it completely);
+ *   border points    = non-core points with a core neighbour: they take the label of the first
+ *                      cluster whose expansion reaches them = the LOWEST-numbered cluster among
+ *                      their core neighbours; everything else is noise.
+ * Arithmetic here: squared distance = sum_k ((double)a_k - (double)b_k)^2, k ascending, in
+ * double without fma, compared with (double)eps*(double)eps.  tests/test_dbscan_oracle.py pins
+ * this against scikit-learn's own output on the committed fixtures.
+ * ======================================================================== */
+
+/* numpy's float32 pairwise summation (numpy/_core/src/umath/loops_utils.h.src), the order
+ * np.linalg.norm(x, axis=1) sums the squares in (reference inference.py:124). */
+static float np_pairwise_sum_f32(const float *a, long n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8];
+        long i;
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+/* out[i] = emb[i] / (||emb[i]||_2 + 1e-8), all in float32 as numpy evaluates it. */
+int orc_normalize_rows(const float *emb, long N, int D, float *out) {
+    if (D < 1 || D > 4096) return 1;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i) {
+        float sq[4096];
+        for (int k = 0; k < D; ++k) sq[k] = emb[i * D + k] * emb[i * D + k];
+        const float nrm = sqrtf(np_pairwise_sum_f32(sq, D));
+        const float den = nrm + 1e-8f;
+        for (int k = 0; k < D; ++k) out[i * D + k] = emb[i * D + k] / den;
+    }
+    return 0;
+}
+
+static inline int orc_within(const float *x, int D, long i, long j, double eps2) {
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const double d = (double)x[i * D + k] - (double)x[j * D + k];
+        s += d * d;
+    }
+    return s <= eps2;
+}
+
+static long orc_find(int32_t *parent, long i) {
+    while (parent[i] != i) {
+        parent[i] = parent[parent[i]];
+        i = parent[i];
+    }
+    return i;
+}
+
+/* x (N,D): ALREADY normalised rows.  labels (N): 0 noise, clusters 1.. in scikit-learn order.
+ * counts (N, may be NULL): neighbourhood sizes.  Two brute-force passes, no adjacency stored. */
+int orc_dbscan(const float *x, long N, int D, double eps, int min_samples, int32_t *labels, int32_t *counts) {
+    if (N < 0 || D < 1 || min_samples < 1) return 1;
+    const double eps2 = eps * eps;
+    int32_t *cnt = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+    int32_t *parent = (int32_t *)malloc((size_t)(N > 0 ? N : 1) * sizeof(int32_t));
+    if (!cnt || !parent) { free(cnt); free(parent); return 2; }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < N; ++i) {
+        int c = 0;
+        for (long j = 0; j < N; ++j) c += orc_within(x, D, i, j, eps2);
+        cnt[i] = c;
+    }
+    for (long i = 0; i < N; ++i) parent[i] = (int32_t)i;
+    /* components of the core graph: min-index root (serial unions; the distance tests are the cost) */
+    for (long i0 = 0; i0 < N; i0 += 256) {
+        const long i1 = i0 + 256 < N ? i0 + 256 : N;
+        /* edge bitmap of this row block against all earlier-or-equal columns, computed in parallel */
+        unsigned char *edge = (unsigned char *)calloc((size_t)(i1 - i0) * (size_t)N, 1);
+        if (!edge) { free(cnt); free(parent); return 2; }
+#pragma omp parallel for schedule(dynamic, 4)
+        for (long i = i0; i < i1; ++i) {
+            if (cnt[i] < min_samples) continue;
+            for (long j = 0; j < i; ++j)
+                if (cnt[j] >= min_samples && orc_within(x, D, i, j, eps2)) edge[(i - i0) * N + j] = 1;
+        }
+        for (long i = i0; i < i1; ++i)
+            for (long j = 0; j < i; ++j)
+                if (edge[(i - i0) * N + j]) {
+                    long a = orc_find(parent, i), b = orc_find(parent, j);
+                    if (a != b) { if (a < b) parent[b] = (int32_t)a; else parent[a] = (int32_t)b; }
+                }
+        free(edge);
+    }
+    /* number the clusters by ascending root (= lowest core index of the component) */
+    int32_t next = 0;
+    for (long i = 0; i < N; ++i) labels[i] = 0;
+    for (long i = 0; i < N; ++i)
+        if (cnt[i] >= min_samples && orc_find(parent, i) == i) labels[i] = ++next;
+    for (long i = 0; i < N; ++i)
+        if (cnt[i] >= min_samples) labels[i] = labels[orc_find(parent, i)];
+    /* border points: lowest-numbered cluster among the core neighbours */
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < N; ++i) {
+        if (cnt[i] >= min_samples) continue;
+        int32_t best = 0;
+        for (long j = 0; j < N; ++j)
+            if (cnt[j] >= min_samples && (best == 0 || labels[j] < best) && orc_within(x, D, i, j, eps2)) best = labels[j];
+        labels[i] = best;
+    }
+    if (counts) for (long i = 0; i < N; ++i) counts[i] = cnt[i];
+    free(cnt);
+    free(parent);
+    return 0;
+}

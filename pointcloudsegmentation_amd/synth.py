@@ -65,3 +65,31 @@ def make_labels(b: int, n: int, seed: int, num_instances: int = 33) -> np.ndarra
     (reference analysis_results/dataset_statistics.txt:7)."""
     rng = np.random.default_rng([seed, 7919])
     return rng.integers(0, num_instances, size=(b, n)).astype(np.int64)
+
+
+def make_embeddings(n: int, d: int, seed: int, n_clusters: int = 33, noise_frac: float = 0.1,
+                    spread=(0.02, 0.12), intrinsic_dim: int = 4) -> np.ndarray:
+    """Instance-embedding-shaped rows (n, d) fp32: `n_clusters` directions on the unit sphere,
+    each with its own spread inside a random `intrinsic_dim`-dimensional subspace (density falls
+    off smoothly, so at DBSCAN eps = 0.1 there are dense cores, border points, noise tails and
+    clusters that touch), plus `noise_frac` of uniformly random directions; rows carry
+    random positive lengths so the caller's L2 normalisation matters.  Cluster sizes are
+    uneven (ScanNet instances: a few large structures, many small objects)."""
+    rng = np.random.default_rng(seed)
+    n_noise = int(n * noise_frac)
+    n_in = n - n_noise
+    centres = rng.standard_normal((max(n_clusters, 1), d))
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    w = rng.gamma(1.0, 1.0, size=max(n_clusters, 1)) + 0.05
+    which = rng.choice(max(n_clusters, 1), size=n_in, p=w / w.sum())
+    sig = rng.uniform(spread[0], spread[1], size=max(n_clusters, 1))
+    q = max(1, min(intrinsic_dim, d))
+    basis = rng.standard_normal((max(n_clusters, 1), q, d))
+    basis /= np.linalg.norm(basis, axis=2, keepdims=True)
+    low = rng.standard_normal((n_in, q)) * (sig[which] / np.sqrt(2.0 * q))[:, None]   # typical pair distance = sig
+    pts = centres[which] + np.einsum("nq,nqd->nd", low, basis[which])
+    noise = rng.standard_normal((n_noise, d))
+    allp = np.concatenate([pts, noise], 0)
+    allp /= np.linalg.norm(allp, axis=1, keepdims=True)
+    allp *= rng.uniform(0.5, 3.0, size=(n, 1))
+    return np.ascontiguousarray(allp[rng.permutation(n)], dtype=np.float32)
