@@ -156,10 +156,30 @@ int p2n_pointwise_layer(const float *in, int B, int Cin, long L, const float *W,
                         void *workspace, size_t workspace_bytes, void *stream);
 int p2n_group_max(const float *in, int B, int C, int M, int ns, float *out, void *stream);
 
+/* ---- embedding clustering ---------------------
+ * p2n_normalize_rows: out[i] = emb[i] / (||emb[i]||_2 + 1e-8) in float32, summed in numpy's
+ * pairwise order = reference inference.py:124 bit for bit.  emb, out (N,D), 1 <= D <= 256.
+ * p2n_cluster_embeddings: reference inference.py:106-142 (cluster_embeddings): that
+ * normalisation, scikit-learn DBSCAN(eps, min_samples) semantics (neighbourhood includes the
+ * point, ||a-b|| <= eps decided in float64; clusters numbered by their lowest core index;
+ * border points join the lowest-numbered cluster among their core neighbours) and the
+ * reference's relabelling: labels (N) int32, 0 = noise, clusters 1..K; *num_clusters = K
+ * (device pointer, may be NULL).  eps is a double because the reference passes a Python float.
+ * p2n_cluster_counts copies out the neighbourhood sizes the last call left in `workspace`. */
+int p2n_normalize_rows(const float *emb, long N, int D, float *out, void *stream);
+size_t p2n_cluster_workspace_bytes(long N, int D, int min_samples);
+int p2n_cluster_embeddings(const float *emb, long N, int D, double eps, int min_samples,
+                           int32_t *labels, int32_t *num_clusters,
+                           void *workspace, size_t workspace_bytes, void *stream);
+int p2n_cluster_counts(const void *workspace, long N, int D, int min_samples, int32_t *counts, void *stream);
+/* Slow-path counters of the last call (device uint64[4]): pairs decided in float64 in the count
+ * pass, in the link pass, union attempts, border-neighbour records. */
+int p2n_cluster_stats(const void *workspace, long N, int D, int min_samples, uint64_t *stats, void *stream);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * While enabled, every kernel launch is bracketed by HIP events on its stream.
  * p2n_profile_collect synchronises and fills, per kernel id (0 encoder, 1 mid,
- * 2 head, 3 fps, 5 knn), the summed milliseconds and the number of launches since
+ * 2 head, 3 fps, 5 knn, 10 cluster prep, 11 cluster count pass, 12 cluster link pass), the summed milliseconds and the number of launches since
  * the last collect.  HOST pointers.  Not thread-safe; off by default. */
 int p2n_profile_enable(int on);
 int p2n_profile_collect(int max_ids, float *ms_sum_host, int *count_host);

@@ -1,0 +1,524 @@
+// Embedding clustering on gfx950 (MI355X): reference inference.py:106-142
+// (cluster_embeddings) = row L2-normalisation (:124) + scikit-learn
+// DBSCAN(eps, min_samples).fit_predict (:127-128) + relabel noise -> 0, clusters -> 1..
+// (:131-140).  SURVEY.md section 8f rank 1; oracle/p2n_oracle.c (orc_dbscan) is the CPU
+// restatement this is tested against, itself pinned on scikit-learn's output.
+//
+// DBSCAN is brute force here, as in scikit-learn for D > 15: two passes over all N x N pairs,
+// each a Gram-matrix GEMM on the exact-fp32 MFMA (d2 = |a|^2 + |b|^2 - 2 a.b), never storing
+// distances or adjacency:
+//   pass 1 (count) neighbourhood sizes -> core flags;
+//   pass 2 (link)  core-core edges -> lock-free union-find whose roots are the LOWEST index of
+//                  their component (scikit-learn numbers clusters by that index); non-core rows
+//                  record their (< min_samples) core neighbours for the border rule.
+// A pair whose fp32 d2 lies within `tau` of eps^2 is decided by an exact recomputation in
+// double (sum_k ((double)a_k-(double)b_k)^2, k ascending, no fma): the arithmetic of the
+// oracle, so labels are bit-identical to it.
+//
+// Layout: the normalised rows are stored once as MFMA fragments
+//   Xp[tile = point/32][g = k/8][lane = 32*h + point%32][j]  = x[point][8g + 4h + j]
+// (1 KiB per fragment, lane-linear), which is both the A operand a wave keeps in registers
+// (its 32 rows) and the B operand streamed through LDS by LDS-DMA, 32 fragments (one block of
+// 128/64/32 columns for D <= 64/128/256) per step, double buffered.  D[row][col]: lane = column,
+// register 4g'+j' of lane half h = row 8g'+4h+j'.
+#include "p2n_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+typedef __attribute__((address_space(3))) void cl_lds_void;
+typedef const __attribute__((address_space(1))) void cl_gbl_void;
+
+#define CL_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CL_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// ------------------------------------------------------------------ normalise + pack
+// numpy's float32 pairwise sum of squares over e[0..n) (n <= 128): the order np.linalg.norm sums in
+__device__ __forceinline__ float cl_np_block_sumsq(const float *e, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, __fmul_rn(e[i], e[i]));
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fmul_rn(e[j], e[j]);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], __fmul_rn(e[i + j], e[i + j]));
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    for (; i < n; ++i) res = __fadd_rn(res, __fmul_rn(e[i], e[i]));
+    return res;
+}
+
+// numpy recurses above 128 elements (halves rounded down to a multiple of 8); two levels cover n <= 256
+template <int LEVELS>
+__device__ __forceinline__ float cl_np_sumsq(const float *e, int n) {
+    if (n <= 128) return cl_np_block_sumsq(e, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    if constexpr (LEVELS > 0)
+        return __fadd_rn(cl_np_sumsq<LEVELS - 1>(e, n2), cl_np_sumsq<LEVELS - 1>(e + n2, n - n2));
+    else
+        return __builtin_nanf("");   // unreachable for n <= 256
+}
+
+// thread per point.  out_rm (N,D) row-major and/or the fragment image Xp + fp32 squared norms.
+__global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restrict__ emb, long N, long Npad, int D, int G,
+                                                           float *__restrict__ out_rm, float *__restrict__ Xp,
+                                                           float *__restrict__ nrm) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    if (i >= N) {   // pad rows: zero vectors that are never anybody's neighbour
+        if (Xp) {
+            for (int k = 0; k < G * 8; k += 4) {
+                const int g = k >> 3, h = (k >> 2) & 1;
+                *reinterpret_cast<f32x4 *>(Xp + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            nrm[i] = __builtin_inff();
+        }
+        return;
+    }
+    const float *e = emb + i * D;
+    const float ss = cl_np_sumsq<2>(e, D);
+    // sqrt and divide through double: correctly rounded in fp32 (53 >= 2*24+2) whatever the fp32 fast paths do
+    const float den = __fadd_rn((float)sqrt((double)ss), 1e-8f);
+    double sq = 0.0;
+    for (int k = 0; k < G * 8; k += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = (k + j < D) ? (float)((double)e[k + j] / (double)den) : 0.f;
+            sq += (double)v[j] * (double)v[j];
+            if (out_rm && k + j < D) out_rm[i * D + k + j] = v[j];
+        }
+        if (Xp) {
+            const int g = k >> 3, h = (k >> 2) & 1;
+            *reinterpret_cast<f32x4 *>(Xp + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = v;
+        }
+    }
+    if (Xp) nrm[i] = (float)sq;
+}
+
+// ------------------------------------------------------------------ exact pair test
+__device__ __noinline__ bool cl_exact_within(const float *__restrict__ Xp, int G, long i, long j, double eps2) {
+    const float *pa = Xp + ((i >> 5) * G * 64 + (i & 31)) * 4;
+    const float *pb = Xp + ((j >> 5) * G * 64 + (j & 31)) * 4;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g)
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(pa + g * 256 + h * 128);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(pb + g * 256 + h * 128);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double d = (double)a[q] - (double)b[q];
+                s += d * d;   // -ffp-contract=off: separate multiply and add, as the oracle
+            }
+        }
+    return s <= eps2;
+}
+
+// ------------------------------------------------------------------ union-find (roots = lowest index)
+__device__ __forceinline__ int cl_find(int *parent, int x) {
+    int p = CL_LD(parent + x);
+    while (p != x) {
+        const int gp = CL_LD(parent + p);
+        if (gp != p) CL_ST(parent + x, gp);   // path halving; any ancestor is a valid parent
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+
+__device__ __noinline__ int cl_unite(int *parent, int i, int j) {
+    int a = cl_find(parent, i), b = cl_find(parent, j);
+    while (a != b) {
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        const int old = atomicCAS(parent + hi, hi, lo);   // hook the larger root under the smaller index
+        if (old == hi) return lo;
+        a = cl_find(parent, old);
+        b = cl_find(parent, lo);
+    }
+    return a;
+}
+
+// ------------------------------------------------------------------ the pair pass
+struct ClArgs {
+    const float *Xp;
+    const float *nrm_row;   // squared norms of the rows (+inf on pad rows)
+    const float *nrm_col;   // squared norms of the columns (+inf: pad; pass 2: also non-core)
+    long Npad;
+    float eps2f, tau;
+    double eps2;
+    int *cnt;               // pass 1: neighbourhood sizes (atomicAdd across column splits)
+    int *parent;            // pass 2
+    const unsigned char *core;
+    const int *colblk_has_core;   // pass 2: per block of 128 columns
+    int *nbr_cnt, *nbr;     // pass 2: core neighbours of non-core rows, `cap` slots per row
+    int cap;
+    int nsplit;
+    unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
+};
+
+template <int G, int CT, int MODE>
+__global__ __launch_bounds__(256, 2) void cl_pair_kernel(ClArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x 32 fragments
+    static_assert(G * CT == 32, "a column block is 32 fragments");
+    constexpr int JB = CT * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const long i0 = ((long)blockIdx.x * 4 + wave) * 32;
+
+    const long nblk = A.Npad / JB;
+    const long jb0 = nblk * blockIdx.y / A.nsplit, jb1 = nblk * (blockIdx.y + 1) / A.nsplit;
+    const long len = jb1 - jb0;
+    if (len <= 0) return;
+    long cur = ((long)blockIdx.x * (128 / JB)) % len;   // staggered start: neighbours in the grid walk different blocks
+
+    auto stage = [&](long jb, int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int f = wave * 8 + q;
+            __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xp + (jb * 32 + f) * 256 + lane * 4),
+                                             (cl_lds_void *)(lds + buf * 8192 + f * 256), 16, 0, 0);
+        }
+    };
+    stage(jb0 + cur, 0);
+
+    f32x4 a[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4 *>(A.Xp + ((i0 >> 5) * G + g) * 256 + lane * 4);
+    float thr[16];
+    unsigned rcore = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = i0 + 8 * (r >> 2) + 4 * h + (r & 3);
+        thr[r] = A.eps2f - A.nrm_row[row];   // pad rows: -inf
+        if (MODE == 1 && A.core[row]) rcore |= 1u << r;
+    }
+    int cl[16], ch[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cl[r] = ch[r] = 0;
+
+    for (long t = 0; t < len; ++t) {
+        const long jb = jb0 + cur;
+        const long nxt = (cur + 1 == len) ? 0 : cur + 1;
+        __syncthreads();   // block jb has landed (vmcnt(0) + barrier); the other buffer is free
+        if (t + 1 < len) stage(jb0 + nxt, (int)((t + 1) & 1));
+        cur = nxt;
+        if (MODE == 1 && !A.colblk_has_core[(jb * JB) >> 7]) continue;
+        const float *buf = lds + (t & 1) * 8192;
+        float ncol[CT];
+        int pj[CT], pi[16];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            ncol[ct] = A.nrm_col[jb * JB + ct * 32 + c];
+            if (MODE == 1) pj[ct] = CL_LD(A.parent + jb * JB + ct * 32 + c);
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pi[r] = CL_LD(A.parent + i0 + 8 * (r >> 2) + 4 * h + (r & 3));
+        }
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x4 b[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) b[ct] = *reinterpret_cast<const f32x4 *>(buf + (ct * G + g) * 256 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)   // round-robin over the CT independent accumulators
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA32(a[g][q], b[ct][q], acc[ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const long col = jb * JB + ct * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float u = fmaf(-2.f, acc[ct][r], ncol[ct]) - thr[r];   // d2 - eps^2 (fp32 estimate)
+                const long row = i0 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (MODE == 0) {
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(u <= -A.tau);
+                    const unsigned long long mh = __builtin_amdgcn_ballot_w64(u <= A.tau);
+                    if (m != mh) {   // rare: some lane sits in the uncertainty band
+                        bool e = false;
+                        if (u <= A.tau && !(u <= -A.tau)) {
+                            e = cl_exact_within(A.Xp, G, row, col, A.eps2);
+                            atomicAdd(A.stats + 0, 1ull);
+                        }
+                        m |= __builtin_amdgcn_ballot_w64(e);
+                    }
+                    cl[r] += __builtin_popcount((unsigned)m);
+                    ch[r] += __builtin_popcount((unsigned)(m >> 32));
+                } else {
+                    if (u <= A.tau && pi[r] != pj[ct]) {
+                        bool e = u <= -A.tau;
+                        if (!e) {
+                            e = cl_exact_within(A.Xp, G, row, col, A.eps2);
+                            atomicAdd(A.stats + 1, 1ull);
+                        }
+                        if (e) {
+                            if (rcore >> r & 1) {
+                                pj[ct] = cl_unite(A.parent, (int)row, (int)col);
+                                atomicAdd(A.stats + 2, 1ull);
+                            } else {
+                                atomicAdd(A.stats + 3, 1ull);
+                                const int slot = atomicAdd(A.nbr_cnt + row, 1);
+                                if (slot < A.cap) A.nbr[row * A.cap + slot] = (int)col;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 0 && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = i0 + 8 * (r >> 2) + (r & 3);
+            if (cl[r]) atomicAdd(A.cnt + row, cl[r]);
+            if (ch[r]) atomicAdd(A.cnt + row + 4, ch[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ glue kernels
+// after pass 1: core flags, column norms with non-core masked out, union-find initial state
+__global__ __launch_bounds__(256) void cl_prepare_link_kernel(const int *__restrict__ cnt, const float *__restrict__ nrm, long N,
+                                                              long Npad, int min_samples, unsigned char *__restrict__ core,
+                                                              float *__restrict__ nrm_core, int *__restrict__ parent,
+                                                              int *__restrict__ nbr_cnt, int *__restrict__ blk_has_core) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    const bool k = i < N && cnt[i] >= min_samples;
+    core[i] = k;
+    nrm_core[i] = k ? nrm[i] : __builtin_inff();
+    parent[i] = (int)i;
+    nbr_cnt[i] = 0;
+    if (k) blk_has_core[i >> 7] = 1;   // benign race: everybody writes 1
+}
+
+// roots -> consecutive cluster numbers 1.. in ascending root order (single workgroup scan)
+__global__ __launch_bounds__(1024) void cl_rank_kernel(int *__restrict__ parent, const unsigned char *__restrict__ core, long N,
+                                                       int *__restrict__ rank, int *__restrict__ num_clusters) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (long s = 0; s < N; s += 1024) {
+        const long i = s + threadIdx.x;
+        int root = 0;
+        if (i < N && core[i]) {
+            const int r = cl_find(parent, (int)i);
+            parent[i] = r;                       // flattened: every core point names its root
+            root = (r == (int)i);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(root);
+        const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (root) rank[i] = off + before + 1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && num_clusters) *num_clusters = base;
+}
+
+__global__ __launch_bounds__(256) void cl_label_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
+                                                       const int *__restrict__ rank, const int *__restrict__ nbr_cnt,
+                                                       const int *__restrict__ nbr, int cap, long N, int32_t *__restrict__ labels) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    if (core[i]) {
+        labels[i] = rank[parent[i]];
+        return;
+    }
+    int n = nbr_cnt[i];
+    n = n < cap ? n : cap;
+    int best = 0x7fffffff;   // lowest root = lowest-numbered cluster among the core neighbours
+    for (int q = 0; q < n; ++q) {
+        const int r = parent[nbr[i * cap + q]];
+        best = r < best ? r : best;
+    }
+    labels[i] = n > 0 ? rank[best] : 0;
+}
+
+// ------------------------------------------------------------------ host side
+struct ClWs {
+    float *Xp, *nrm, *nrm_core;
+    int *cnt, *parent, *nbr_cnt, *rank, *blk_has_core, *nbr;
+    unsigned char *core;
+    unsigned long long *stats;
+};
+
+static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + o : nullptr;
+        o += (bytes + 255) / 256 * 256;
+        return p;
+    };
+    w.Xp = (float *)take(sizeof(float) * (size_t)Npad * G * 8);
+    w.nrm = (float *)take(sizeof(float) * Npad);
+    w.nrm_core = (float *)take(sizeof(float) * Npad);
+    w.cnt = (int *)take(sizeof(int) * Npad);
+    w.parent = (int *)take(sizeof(int) * Npad);
+    w.nbr_cnt = (int *)take(sizeof(int) * Npad);
+    w.rank = (int *)take(sizeof(int) * Npad);
+    w.blk_has_core = (int *)take(sizeof(int) * (Npad / 128 + 1));
+    w.core = (unsigned char *)take((size_t)Npad);
+    w.stats = (unsigned long long *)take(sizeof(unsigned long long) * 8);
+    w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
+    return o;
+}
+
+static int cl_geometry(int D, int &G, int &CT) {
+    if (D <= 64) { G = 8; CT = 4; }
+    else if (D <= 128) { G = 16; CT = 2; }
+    else { G = 32; CT = 1; }
+    return 0;
+}
+
+static int cl_check(const char *fn, long N, int D, double eps, int min_samples) {
+    P2N_REQUIRE(N >= 0 && N <= 0x7fffff00L, "%s: N=%ld out of range", fn, N);
+    P2N_REQUIRE(D >= 1 && D <= 256, "%s: D=%d not in 1..256", fn, D);
+    P2N_REQUIRE(eps > 0.0 && eps < 1e3, "%s: eps=%g must be positive", fn, eps);
+    P2N_REQUIRE(min_samples >= 1 && min_samples <= 65536, "%s: min_samples=%d not in 1..65536", fn, min_samples);
+    return P2N_OK;
+}
+
+extern "C" size_t p2n_cluster_workspace_bytes(long N, int D, int min_samples) {
+    if (N < 0 || D < 1 || D > 256 || min_samples < 1) return 0;
+    int G, CT;
+    cl_geometry(D, G, CT);
+    ClWs w;
+    return cl_carve(w, nullptr, (N + 127) / 128 * 128, G, N, min_samples - 1);
+}
+
+extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, void *stream_) {
+    P2N_REQUIRE(N >= 0 && D >= 1 && D <= 256, "p2n_normalize_rows: N=%ld D=%d (D in 1..256)", N, D);
+    if (N == 0) return P2N_OK;
+    P2N_REQUIRE(emb && out, "p2n_normalize_rows: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(cl_normalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, N, D, (D + 7) / 8,
+                       out, (float *)nullptr, (float *)nullptr);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+template <int G, int CT>
+static int cl_launch_pairs(int mode, const ClArgs &a, long nrowblk, hipStream_t stream) {
+    const size_t ldsb = 2 * 32 * 1024;
+    if (mode == 0)
+        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 0>), dim3((unsigned)nrowblk, a.nsplit), dim3(256), ldsb, stream, a);
+    else
+        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 1>), dim3((unsigned)nrowblk, a.nsplit), dim3(256), ldsb, stream, a);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double eps, int min_samples, int32_t *labels,
+                                      int32_t *num_clusters, void *workspace, size_t workspace_bytes, void *stream_) {
+    int rc = cl_check("p2n_cluster_embeddings", N, D, eps, min_samples);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) {
+        if (num_clusters) P2N_CHECK_HIP(hipMemsetAsync(num_clusters, 0, sizeof(int32_t), stream));
+        return P2N_OK;
+    }
+    P2N_REQUIRE(emb && labels && workspace, "p2n_cluster_embeddings: null pointer");
+    int G, CT;
+    cl_geometry(D, G, CT);
+    const long Npad = (N + 127) / 128 * 128;
+    const int cap = min_samples - 1;
+    ClWs w;
+    const size_t need = cl_carve(w, (char *)workspace, Npad, G, N, cap);
+    if (workspace_bytes < need) {
+        p2n_set_error("p2n_cluster_embeddings: workspace %zu < %zu bytes", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    const unsigned nb256 = (unsigned)((Npad + 255) / 256);
+    int ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
+    hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm);
+    P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
+    P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
+    P2N_CHECK_HIP(hipMemsetAsync(w.blk_has_core, 0, sizeof(int) * (Npad / 128 + 1), stream));
+    p2n_prof_end(ps, stream);
+
+    ClArgs a;
+    a.Xp = w.Xp; a.nrm_row = w.nrm; a.nrm_col = w.nrm; a.Npad = Npad;
+    a.eps2 = eps * eps;
+    a.eps2f = (float)a.eps2;
+    a.tau = 2.5e-5f * (float)(G / 8);   // > 2 * (8G) * 2^-24 (dot of unit vectors) + norm and threshold roundings
+    a.cnt = w.cnt; a.parent = w.parent; a.core = w.core; a.colblk_has_core = w.blk_has_core;
+    a.nbr_cnt = w.nbr_cnt; a.nbr = w.nbr; a.cap = cap; a.stats = w.stats;
+    const long nrowblk = Npad / 128;
+    long ns = (2048 + nrowblk - 1) / nrowblk;            // enough workgroups to fill 256 CUs x 2 several times
+    const long ncolblk = Npad / (CT * 32);
+    a.nsplit = (int)(ns < 1 ? 1 : (ns > ncolblk ? ncolblk : ns));
+
+    ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
+    if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, nrowblk, stream);
+    else if (G == 16) rc = cl_launch_pairs<16, 2>(0, a, nrowblk, stream);
+    else rc = cl_launch_pairs<32, 1>(0, a, nrowblk, stream);
+    p2n_prof_end(ps, stream);
+    if (rc) return rc;
+
+    hipLaunchKernelGGL(cl_prepare_link_kernel, dim3(nb256), dim3(256), 0, stream, w.cnt, w.nrm, N, Npad, min_samples, w.core,
+                       w.nrm_core, w.parent, w.nbr_cnt, w.blk_has_core);
+    a.nrm_col = w.nrm_core;
+    ps = p2n_prof_begin(P2N_K_CLUSTER_LINK, stream);
+    if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, nrowblk, stream);
+    else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, nrowblk, stream);
+    else rc = cl_launch_pairs<32, 1>(1, a, nrowblk, stream);
+    p2n_prof_end(ps, stream);
+    if (rc) return rc;
+
+    ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
+    hipLaunchKernelGGL(cl_rank_kernel, dim3(1), dim3(1024), 0, stream, w.parent, w.core, N, w.rank, num_clusters);
+    hipLaunchKernelGGL(cl_label_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.parent, w.core, w.rank,
+                       w.nbr_cnt, w.nbr, cap, N, labels);
+    p2n_prof_end(ps, stream);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+// neighbourhood sizes of the last p2n_cluster_embeddings call on this workspace (test / diagnostics aid)
+extern "C" int p2n_cluster_counts(const void *workspace, long N, int D, int min_samples, int32_t *counts, void *stream_) {
+    P2N_REQUIRE(N >= 0 && D >= 1 && D <= 256 && min_samples >= 1, "p2n_cluster_counts: bad arguments");
+    if (N == 0) return P2N_OK;
+    int G, CT;
+    cl_geometry(D, G, CT);
+    ClWs w;
+    cl_carve(w, (char *)workspace, (N + 127) / 128 * 128, G, N, min_samples - 1);
+    P2N_CHECK_HIP(hipMemcpyAsync(counts, w.cnt, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    return P2N_OK;
+}
+
+// slow-path counters of the last call: stats[0] pairs decided in double in pass 1, [1] in pass 2,
+// [2] union attempts, [3] border-neighbour records (device pointer to 4 x uint64)
+extern "C" int p2n_cluster_stats(const void *workspace, long N, int D, int min_samples, uint64_t *stats, void *stream_) {
+    P2N_REQUIRE(N >= 0 && D >= 1 && D <= 256 && min_samples >= 1 && stats, "p2n_cluster_stats: bad arguments");
+    if (N == 0) {
+        P2N_CHECK_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint64_t), (hipStream_t)stream_));
+        return P2N_OK;
+    }
+    int G, CT;
+    cl_geometry(D, G, CT);
+    ClWs w;
+    cl_carve(w, (char *)workspace, (N + 127) / 128 * 128, G, N, min_samples - 1);
+    P2N_CHECK_HIP(hipMemcpyAsync(stats, w.stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    return P2N_OK;
+}
