@@ -176,6 +176,16 @@ int p2n_cluster_counts(const void *workspace, long N, int D, int min_samples, in
  * pass, in the link pass, union attempts, border-neighbour records. */
 int p2n_cluster_stats(const void *workspace, long N, int D, int min_samples, uint64_t *stats, void *stream);
 
+/* ---- input normalisation -------------------------
+ * reference inference.py:76-104 (preprocess_point_cloud): points (N,3) float64, colors (N,3)
+ * float64 or NULL (-> 0.5) -> features (N,6) float32 = [(points - mean) / max|points - mean| ,
+ * colors (/255 when colors.max() > 1)], bit-identical to numpy's float64 evaluation (the row
+ * sum is replayed in numpy's order).  centroid_scale (device double[4], may be NULL) receives
+ * {cx, cy, cz, scale}, the reference's second and third return values. */
+size_t p2n_preprocess_workspace_bytes(void);
+int p2n_preprocess_points(const double *points, const double *colors, long N, float *features,
+                          double *centroid_scale, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * While enabled, every kernel launch is bracketed by HIP events on its stream.
  * p2n_profile_collect synchronises and fills, per kernel id (0 encoder, 1 mid,

@@ -85,6 +85,7 @@ static inline P2nLayout p2n_make_layout(int F, int E) {
 #define P2N_K_CLUSTER_PREP 10
 #define P2N_K_CLUSTER_COUNT 11
 #define P2N_K_CLUSTER_LINK 12
+#define P2N_K_PREP 13
 #define P2N_K_COUNT 32
 int p2n_prof_begin(int kernel_id, hipStream_t s);
 void p2n_prof_end(int slot, hipStream_t s);

@@ -1,0 +1,48 @@
+"""Input normalisation on the GPU: drop-in for the reference's
+`PointCloudInference.preprocess_point_cloud` (reference inference.py:76-104).
+Runs in libp2n_hip.so (csrc/p2n_prep.hip); no CPU path: without a GPU the call raises.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import runtime as _rt
+
+
+def _f64_device(a, name):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        if not torch.cuda.is_available():
+            raise RuntimeError("preprocess_point_cloud: needs a GPU (the HIP library is the only implementation)")
+        a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    if not (isinstance(a, torch.Tensor) and a.is_cuda):
+        raise ValueError(f"{name} must be a numpy array or a GPU tensor")
+    a = a.to(torch.float64).contiguous()
+    if a.dim() != 2 or a.size(1) != 3:
+        raise ValueError(f"{name} must be (N,3), got {tuple(a.shape)}")
+    return a
+
+
+def preprocess_point_cloud(points, colors=None):
+    """points (N,3), colors (N,3) or None -> (features (1,N,6) float32 GPU tensor, centroid (3,)
+    float64 numpy, scale float64): the reference's three return values, bit-identical to its
+    numpy float64 evaluation.  The reference returns a CPU tensor that its caller moves to the
+    device (inference.py:169); here it is already there."""
+    p = _f64_device(points, "points")
+    c = _f64_device(colors, "colors")
+    n = p.size(0)
+    if n < 1:
+        raise ValueError("points is empty")
+    if c is not None and c.size(0) != n:
+        raise ValueError("points and colors differ in length")
+    L = _lib.lib()
+    feat = torch.empty((1, n, 6), dtype=torch.float32, device=p.device)
+    cs = torch.empty(4, dtype=torch.float64, device=p.device)
+    ws = _rt.workspace(L.p2n_preprocess_workspace_bytes(), p.device)
+    with torch.cuda.device(p.device):
+        _lib.check(L.p2n_preprocess_points(p.data_ptr(), c.data_ptr() if c is not None else None, n, feat.data_ptr(),
+                                           cs.data_ptr(), ws.data_ptr(), ws.numel(), _rt.stream_handle(p.device)),
+                   "p2n_preprocess_points")
+    h = cs.cpu().numpy()
+    return feat, h[:3].copy(), np.float64(h[3])
