@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""BASELINE configs[0] shape: one 166,499-point scene through normalise -> Point2Net -> cluster
+(reference inference.py:143-188), everything on one MI355X; the reference's CPU path (stock
+PyTorch forward; scikit-learn DBSCAN on a subsample) timed beside it.  Prints one JSON line."""
+import argparse, json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+from pointcloudsegmentation_amd.clustering import cluster_embeddings
+from pointcloudsegmentation_amd.inference import predict
+from pointcloudsegmentation_amd.point2net import Point2Net
+from pointcloudsegmentation_amd.preprocess import preprocess_point_cloud
+from pointcloudsegmentation_amd.synth import make_embeddings
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=166499)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--no-cpu", action="store_true")
+a = ap.parse_args()
+rng = np.random.default_rng(0)
+pts = rng.uniform(0, 1, (a.n, 3)) * np.array([8.0, 6.0, 3.0])
+col = rng.integers(0, 256, (a.n, 3)).astype(np.float64)
+w = dict(np.load(os.path.join(REPO, "tests", "golden", "weights.npz")))
+m = Point2Net(feature_dim=6, embedding_dim=64)
+m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+m = m.cuda().eval()
+
+
+def timed(fn, steps):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps, r
+
+
+out = {"metric": "scene inference ms (normalise + forward + cluster)", "n": a.n}
+out["end_to_end_ms_host_in_host_out"], res = timed(lambda: predict(m, pts, col), a.steps)
+out["num_instances"] = res["num_instances"]
+pg, cg = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+out["end_to_end_ms_device_resident"], _ = timed(lambda: predict(m, pg, cg, to_host=False), a.steps)
+out["normalise_ms"], (feat, _, _) = timed(lambda: preprocess_point_cloud(pg, cg), a.steps)
+with torch.no_grad():
+    out["forward_ms"], emb = timed(lambda: m(feat), a.steps)
+out["cluster_ms_model_embeddings"], _ = timed(lambda: cluster_embeddings(emb[0]), a.steps)
+syn = torch.from_numpy(make_embeddings(a.n, 64, 11)).cuda()
+out["cluster_ms_33_cluster_embeddings"], _ = timed(lambda: cluster_embeddings(syn), a.steps)
+if not a.no_cpu:
+    mc = Point2Net(feature_dim=6, embedding_dim=64)
+    mc.load_state_dict(m.state_dict())
+    mc.eval()
+    fc = feat.cpu()
+    with torch.no_grad():
+        mc(fc)
+        t0 = time.perf_counter(); ec = mc(fc); out["cpu_torch_forward_s"] = time.perf_counter() - t0
+    from sklearn.cluster import DBSCAN
+    sub = syn[:30000].cpu().numpy()
+    x = sub / (np.linalg.norm(sub, axis=1, keepdims=True) + 1e-8)
+    t0 = time.perf_counter(); DBSCAN(eps=0.1, min_samples=50, n_jobs=-1).fit_predict(x)
+    out["cpu_sklearn_dbscan_s_30000_subsample"] = time.perf_counter() - t0
+    out["cpu_threads"] = torch.get_num_threads()
+print(json.dumps(out))
