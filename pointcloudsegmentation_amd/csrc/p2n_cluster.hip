@@ -21,6 +21,7 @@
 // (its 32 rows) and the B operand streamed through LDS by LDS-DMA, 32 fragments (one block of
 // 128/64/32 columns for D <= 64/128/256) per step, double buffered.  D[row][col]: lane = column,
 // register 4g'+j' of lane half h = row 8g'+4h+j'.
+#include <type_traits>
 #include "p2n_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
                 const int g = k >> 3, h = (k >> 2) & 1;
                 *reinterpret_cast<f32x4 *>(Xp + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            nrm[i] = __builtin_inff();
+            nrm[i] = -__builtin_inff();
         }
         return;
     }
@@ -97,11 +98,11 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
             *reinterpret_cast<f32x4 *>(Xp + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = v;
         }
     }
-    if (Xp) nrm[i] = (float)sq;
+    if (Xp) nrm[i] = (float)(-0.5 * sq);   // nh = -|x|^2/2, the accumulator start value of the pair passes
 }
 
 // ------------------------------------------------------------------ exact pair test
-__device__ __noinline__ bool cl_exact_within(const float *__restrict__ Xp, int G, long i, long j, double eps2) {
+__device__ __forceinline__ bool cl_exact_within(const float *__restrict__ Xp, int G, long i, long j, double eps2) {
     const float *pa = Xp + ((i >> 5) * G * 64 + (i & 31)) * 4;
     const float *pb = Xp + ((j >> 5) * G * 64 + (j & 31)) * 4;
     double s = 0.0;
@@ -130,7 +131,7 @@ __device__ __forceinline__ int cl_find(int *parent, int x) {
     return x;
 }
 
-__device__ __noinline__ int cl_unite(int *parent, int i, int j) {
+__device__ __forceinline__ int cl_unite(int *parent, int i, int j) {
     int a = cl_find(parent, i), b = cl_find(parent, j);
     while (a != b) {
         const int hi = a > b ? a : b, lo = a > b ? b : a;
@@ -145,8 +146,8 @@ __device__ __noinline__ int cl_unite(int *parent, int i, int j) {
 // ------------------------------------------------------------------ the pair pass
 struct ClArgs {
     const float *Xp;
-    const float *nrm_row;   // squared norms of the rows (+inf on pad rows)
-    const float *nrm_col;   // squared norms of the columns (+inf: pad; pass 2: also non-core)
+    const float *nrm_row;   // nh = -|x|^2/2 of the wave-owned points (-inf on pad rows)
+    const float *nrm_col;   // nh of the streamed points (-inf: pad; pass 2: also non-core)
     long Npad;
     float eps2f, tau;
     double eps2;
@@ -160,14 +161,32 @@ struct ClArgs {
     unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
 };
 
+// Orientation: D = X_J . X_I^T -- the streamed points j are the ROWS of the MFMA result (one per
+// accumulator register), the wave's own 32 points i are the COLUMNS (one per lane; the two lane
+// halves hold different rows j of the same i).  Everything that belongs to i -- threshold,
+// neighbour count, parent -- is therefore per-lane state, and counting is two VALU operations
+// per pair with no cross-lane or scalar work.
+// The accumulators start at nh[j] = -|x_j|^2/2 (staged through LDS with the block), so
+//   d2 <= eps^2  <=>  acc = x_i.x_j - |x_j|^2/2  >=  (|x_i|^2 - eps^2)/2 =: h_i;
+// hd = h + tau/2 (definitely inside), hm = h - tau/2 (maybe inside).
+// Software pipeline over "units" of UT streamed tiles: the MFMAs of one unit are issued
+// interleaved with the compares of the previous unit (two small accumulator sets).
+#define CL_BLK_FLOATS (8192 + 128)   // 32 fragments + nh[128] per LDS buffer
+#define CL_PAR_BASE (2 * CL_BLK_FLOATS)   // then three rotating parent[128] slots (pass 2)
+#define CL_LDS_FLOATS (CL_PAR_BASE + 3 * 128)
+
 template <int G, int CT, int MODE>
 __global__ __launch_bounds__(256, 2) void cl_pair_kernel(ClArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x 32 fragments
-    static_assert(G * CT == 32, "a column block is 32 fragments");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // CL_LDS_FLOATS
+    static_assert(G * CT == 32, "a streamed block is 32 fragments");
     constexpr int JB = CT * 32;
+    constexpr int UT = CT >= 2 ? 2 : 1;   // tiles per unit (independent MFMA chains)
+    constexpr int UPS = CT / UT;          // units per streamed block
+    constexpr int EL = UT * 16;           // pairs per lane per unit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const long i0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long my = i0 + c;               // the point this lane owns
 
     const long nblk = A.Npad / JB;
     const long jb0 = nblk * blockIdx.y / A.nsplit, jb1 = nblk * (blockIdx.y + 1) / A.nsplit;
@@ -176,113 +195,181 @@ __global__ __launch_bounds__(256, 2) void cl_pair_kernel(ClArgs A) {
     long cur = ((long)blockIdx.x * (128 / JB)) % len;   // staggered start: neighbours in the grid walk different blocks
 
     auto stage = [&](long jb, int buf) {
+        float *dst = lds + buf * CL_BLK_FLOATS;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int f = wave * 8 + q;
             __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xp + (jb * 32 + f) * 256 + lane * 4),
-                                             (cl_lds_void *)(lds + buf * 8192 + f * 256), 16, 0, 0);
+                                             (cl_lds_void *)(dst + f * 256), 16, 0, 0);
         }
+        // nh and (pass 2) parent of the block's JB points: waves 0/1 (2/3) move 64 dwords each
+        if (wave * 64 < JB)
+            __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.nrm_col + jb * JB + wave * 64 + lane),
+                                             (cl_lds_void *)(dst + 8192 + wave * 64), 4, 0, 0);
     };
+    // Pass 2 also needs the block's parent[] values.  They must be read coherently (agent scope:
+    // other XCDs' L2s are not snooped by a plain or DMA load), so waves 2/3 fetch them one block
+    // ahead into a register and park them in LDS before the next barrier.  Block t uses slot t % 3:
+    // it is written during step t-1 and still read during step t+1 (the pipelined compares of
+    // the block's last unit), so three slots keep writer and readers apart.
+    const bool pfetch = MODE == 1 && wave >= 2 && (wave - 2) * 64 < JB;
+    const int pslot = CL_PAR_BASE + (wave - 2) * 64 + lane;
     stage(jb0 + cur, 0);
+    if (pfetch) lds[pslot] = __int_as_float(CL_LD(A.parent + (jb0 + cur) * JB + (wave - 2) * 64 + lane));
+    int pnext = 0;
 
     f32x4 a[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4 *>(A.Xp + ((i0 >> 5) * G + g) * 256 + lane * 4);
-    float thr[16];
-    unsigned rcore = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long row = i0 + 8 * (r >> 2) + 4 * h + (r & 3);
-        thr[r] = A.eps2f - A.nrm_row[row];   // pad rows: -inf
-        if (MODE == 1 && A.core[row]) rcore |= 1u << r;
-    }
-    int cl[16], ch[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cl[r] = ch[r] = 0;
+    const float hh = -A.nrm_row[my] - 0.5f * A.eps2f;   // nrm_* hold -|x|^2/2 (-inf on pad rows: h = +inf, nothing reaches it)
+    const float hm = hh - 0.5f * A.tau, hd = hh + 0.5f * A.tau;
+    const bool mycore = MODE == 1 && A.core[my];
+    int cntd = 0, cntm = 0, expdiff = 0;   // pass 1: definite(+resolved) / maybe counts; pass 2: cntm = maybe-edges seen
+    int pi = 0;
 
-    for (long t = 0; t < len; ++t) {
-        const long jb = jb0 + cur;
-        const long nxt = (cur + 1 == len) ? 0 : cur + 1;
-        __syncthreads();   // block jb has landed (vmcnt(0) + barrier); the other buffer is free
-        if (t + 1 < len) stage(jb0 + nxt, (int)((t + 1) & 1));
-        cur = nxt;
-        if (MODE == 1 && !A.colblk_has_core[(jb * JB) >> 7]) continue;
-        const float *buf = lds + (t & 1) * 8192;
-        float ncol[CT];
-        int pj[CT], pi[16];
+    // ---- per-unit pieces --------------------------------------------------
+    auto init_acc = [&](f32x16(&acc)[UT], const float *blk, int u) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            ncol[ct] = A.nrm_col[jb * JB + ct * 32 + c];
-            if (MODE == 1) pj[ct] = CL_LD(A.parent + jb * JB + ct * 32 + c);
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 nh = *reinterpret_cast<const f32x4 *>(blk + 8192 + (u * UT + ut) * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[ut][4 * gq + q] = nh[q];
+            }
+    };
+    auto mfma_slot = [&](f32x16(&acc)[UT], const float *ubuf, int sl) __attribute__((always_inline)) {
+        const int g = sl >> 2, q = sl & 3;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(ubuf + (ut * G + g) * 256 + lane * 4);   // CSE'd over q
+            acc[ut] = MFMA32(b[q], a[g][q], acc[ut]);   // rows = streamed points, columns = this wave's points
         }
-        if (MODE == 1) {
+    };
+    auto fast_pair = [&](const f32x16(&acc)[UT], int e) __attribute__((always_inline)) {
+        const float v = acc[e >> 4][e & 15];
+        if (MODE == 0) cntd += (v >= hd);
+        cntm += (v >= hm);
+    };
+    // a finished unit in which some lane saw an undecided pair (pass 1) or any candidate edge (pass 2)
+    auto slow_unit = [&](const f32x16(&acc)[UT], const float *par, int u, long col0) __attribute__((always_inline)) {
+        unsigned need = 0, sure = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pi[r] = CL_LD(A.parent + i0 + 8 * (r >> 2) + 4 * h + (r & 3));
-        }
-        f32x16 acc[CT];
+        for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 pjv;
+                if (MODE == 1) pjv = *reinterpret_cast<const f32x4 *>(par + (u * UT + ut) * 32 + 8 * gq + 4 * h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            f32x4 b[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) b[ct] = *reinterpret_cast<const f32x4 *>(buf + (ct * G + g) * 256 + lane * 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)   // round-robin over the CT independent accumulators
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA32(a[g][q], b[ct][q], acc[ct]);
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const long col = jb * JB + ct * 32 + c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float u = fmaf(-2.f, acc[ct][r], ncol[ct]) - thr[r];   // d2 - eps^2 (fp32 estimate)
-                const long row = i0 + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (MODE == 0) {
-                    unsigned long long m = __builtin_amdgcn_ballot_w64(u <= -A.tau);
-                    const unsigned long long mh = __builtin_amdgcn_ballot_w64(u <= A.tau);
-                    if (m != mh) {   // rare: some lane sits in the uncertainty band
-                        bool e = false;
-                        if (u <= A.tau && !(u <= -A.tau)) {
-                            e = cl_exact_within(A.Xp, G, row, col, A.eps2);
-                            atomicAdd(A.stats + 0, 1ull);
-                        }
-                        m |= __builtin_amdgcn_ballot_w64(e);
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * gq + q, e = ut * 16 + r;
+                    const float v = acc[ut][r];
+                    if (MODE == 0) {
+                        need |= (unsigned)(v >= hm && !(v >= hd)) << e;
+                    } else {
+                        const bool nd = v >= hm && __float_as_int(pjv[q]) != pi;
+                        need |= (unsigned)nd << e;
+                        sure |= (unsigned)(nd && v >= hd) << e;
                     }
-                    cl[r] += __builtin_popcount((unsigned)m);
-                    ch[r] += __builtin_popcount((unsigned)(m >> 32));
-                } else {
-                    if (u <= A.tau && pi[r] != pj[ct]) {
-                        bool e = u <= -A.tau;
-                        if (!e) {
-                            e = cl_exact_within(A.Xp, G, row, col, A.eps2);
-                            atomicAdd(A.stats + 1, 1ull);
-                        }
-                        if (e) {
-                            if (rcore >> r & 1) {
-                                pj[ct] = cl_unite(A.parent, (int)row, (int)col);
-                                atomicAdd(A.stats + 2, 1ull);
-                            } else {
-                                atomicAdd(A.stats + 3, 1ull);
-                                const int slot = atomicAdd(A.nbr_cnt + row, 1);
-                                if (slot < A.cap) A.nbr[row * A.cap + slot] = (int)col;
-                            }
-                        }
+                }
+            }
+        while (need) {
+            const int e = __builtin_ctz(need);
+            need &= need - 1;
+            const int ut = e >> 4, r = e & 15;
+            const long other = col0 + ut * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (MODE == 0) {
+                atomicAdd(A.stats + 0, 1ull);
+                cntd += cl_exact_within(A.Xp, G, my, other, A.eps2);
+            } else {
+                bool ok = sure >> e & 1;
+                if (!ok) {
+                    ok = cl_exact_within(A.Xp, G, my, other, A.eps2);
+                    atomicAdd(A.stats + 1, 1ull);
+                }
+                if (ok) {
+                    if (mycore) {
+                        pi = cl_unite(A.parent, (int)my, (int)other);
+                        atomicAdd(A.stats + 2, 1ull);
+                    } else {
+                        atomicAdd(A.stats + 3, 1ull);
+                        const int slot = atomicAdd(A.nbr_cnt + my, 1);
+                        if (slot < A.cap) A.nbr[my * A.cap + slot] = (int)other;
                     }
                 }
             }
         }
-    }
-    if (MODE == 0 && lane == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long row = i0 + 8 * (r >> 2) + (r & 3);
-            if (cl[r]) atomicAdd(A.cnt + row, cl[r]);
-            if (ch[r]) atomicAdd(A.cnt + row + 4, ch[r]);
+    };
+
+    // one pipeline stage: GEMM of unit w into `accn` while unit w-1 (in `accp`) is compared
+    const long W = len * UPS;
+    long col0_prev = 0, jb_cur = 0;
+    bool prev_active = false, blk_active = false;
+    const float *par_prev = lds;
+    int u_prev = 0;
+    auto unit_step = [&](f32x16(&accn)[UT], f32x16(&accp)[UT], long w, auto uconst) __attribute__((always_inline)) {
+        bool active = false;
+        const long t = w / UPS;
+        constexpr int u = decltype(uconst)::value;   // w % UPS, known at compile time (w advances in pairs)
+        if (w < W) {
+            if (u == 0) {
+                jb_cur = jb0 + cur;
+                const long nxt = (cur + 1 == len) ? 0 : cur + 1;
+                __syncthreads();   // block jb_cur has landed (vmcnt(0) + barrier); the other buffer is free
+                if (MODE == 1) pi = CL_LD(A.parent + my);   // queued before the DMA: vmcnt completes in order
+                if (pfetch && t + 1 < len) pnext = CL_LD(A.parent + (jb0 + nxt) * JB + (wave - 2) * 64 + lane);
+                if (t + 1 < len) stage(jb0 + nxt, (int)((t + 1) & 1));
+                cur = nxt;
+                blk_active = MODE == 0 || A.colblk_has_core[(jb_cur * JB) >> 7] != 0;
+            }
+            active = blk_active;
         }
+        const float *blk = lds + (t & 1) * CL_BLK_FLOATS;
+        const float *ubuf = blk + u * UT * G * 256;
+        const long col0 = jb_cur * JB + u * UT * 32;
+        const int before = cntm;
+        if (active && prev_active) {   // the steady state: one straight-line block, compares between the MFMAs
+            init_acc(accn, blk, u);
+#pragma unroll
+            for (int sl = 0; sl < 4 * G; ++sl) {
+                mfma_slot(accn, ubuf, sl);
+#pragma unroll
+                for (int e = sl * EL / (4 * G); e < (sl + 1) * EL / (4 * G); ++e) fast_pair(accp, e);
+            }
+        } else {
+            if (active) {
+                init_acc(accn, blk, u);
+#pragma unroll
+                for (int sl = 0; sl < 4 * G; ++sl) mfma_slot(accn, ubuf, sl);
+            }
+            if (prev_active) {
+#pragma unroll
+                for (int e = 0; e < EL; ++e) fast_pair(accp, e);
+            }
+        }
+        if (u == 0 && pfetch && w < W && t + 1 < len)   // parents of the next block -> its LDS buffer (read after the next barrier)
+            lds[(int)((t + 1) % 3) * 128 + pslot] = __int_as_float(pnext);
+        if (prev_active) {
+            const bool trouble = MODE == 0 ? (cntm - cntd != expdiff) : (cntm != before);
+            if (__builtin_amdgcn_ballot_w64(trouble)) {
+                slow_unit(accp, par_prev, u_prev, col0_prev);
+                expdiff = cntm - cntd;
+            }
+        }
+        prev_active = active;
+        col0_prev = col0;
+        par_prev = lds + CL_PAR_BASE + (int)(t % 3) * 128;
+        u_prev = u;
+    };
+
+    f32x16 accA[UT], accB[UT];
+    for (long w = 0; w <= W; w += 2) {
+        unit_step(accA, accB, w, std::integral_constant<int, 0>{});
+        if (w + 1 <= W) unit_step(accB, accA, w + 1, std::integral_constant<int, (UPS > 1 ? 1 : 0)>{});
+    }
+    if (MODE == 0) {
+        cntd += __shfl_xor(cntd, 32);   // the two lane halves saw different rows of the same point
+        if (h == 0 && cntd) atomicAdd(A.cnt + my, cntd);
     }
 }
 
@@ -296,7 +383,7 @@ __global__ __launch_bounds__(256) void cl_prepare_link_kernel(const int *__restr
     if (i >= Npad) return;
     const bool k = i < N && cnt[i] >= min_samples;
     core[i] = k;
-    nrm_core[i] = k ? nrm[i] : __builtin_inff();
+    nrm_core[i] = k ? nrm[i] : -__builtin_inff();
     parent[i] = (int)i;
     nbr_cnt[i] = 0;
     if (k) blk_has_core[i >> 7] = 1;   // benign race: everybody writes 1
@@ -371,10 +458,10 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         return p;
     };
     w.Xp = (float *)take(sizeof(float) * (size_t)Npad * G * 8);
-    w.nrm = (float *)take(sizeof(float) * Npad);
-    w.nrm_core = (float *)take(sizeof(float) * Npad);
+    w.nrm = (float *)take(sizeof(float) * (Npad + 64));        // + 64: the 64-dword block prefetch may overrun
+    w.nrm_core = (float *)take(sizeof(float) * (Npad + 64));
     w.cnt = (int *)take(sizeof(int) * Npad);
-    w.parent = (int *)take(sizeof(int) * Npad);
+    w.parent = (int *)take(sizeof(int) * (Npad + 64));
     w.nbr_cnt = (int *)take(sizeof(int) * Npad);
     w.rank = (int *)take(sizeof(int) * Npad);
     w.blk_has_core = (int *)take(sizeof(int) * (Npad / 128 + 1));
@@ -420,7 +507,11 @@ extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, v
 
 template <int G, int CT>
 static int cl_launch_pairs(int mode, const ClArgs &a, long nrowblk, hipStream_t stream) {
-    const size_t ldsb = 2 * 32 * 1024;
+    const size_t ldsb = CL_LDS_FLOATS * sizeof(float);   // 66 KiB: above the default dynamic-LDS limit
+    P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     if (mode == 0)
         hipLaunchKernelGGL((cl_pair_kernel<G, CT, 0>), dim3((unsigned)nrowblk, a.nsplit), dim3(256), ldsb, stream, a);
     else
