@@ -175,8 +175,12 @@ struct ClArgs {
 #define CL_PAR_BASE (2 * CL_BLK_FLOATS)   // then three rotating parent[128] slots (pass 2)
 #define CL_LDS_FLOATS (CL_PAR_BASE + 3 * 128)
 
+#define CL_NW 4   // waves per workgroup: 128 wave-owned points share one streamed block (6 or 8 waves spill: measured slower)
+#define CL_ROWBLK (CL_NW * 32)
+#define CL_NPAD_UNIT 128   // lcm(CL_ROWBLK, 128): rows pad to whole workgroups and whole streamed blocks
+
 template <int G, int CT, int MODE>
-__global__ __launch_bounds__(256, 2) void cl_pair_kernel(ClArgs A) {
+__global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // CL_LDS_FLOATS
     static_assert(G * CT == 32, "a streamed block is 32 fragments");
     constexpr int JB = CT * 32;
@@ -185,22 +189,27 @@ __global__ __launch_bounds__(256, 2) void cl_pair_kernel(ClArgs A) {
     constexpr int EL = UT * 16;           // pairs per lane per unit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const long i0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long i0 = ((long)blockIdx.x * CL_NW + wave) * 32;
     const long my = i0 + c;               // the point this lane owns
 
     const long nblk = A.Npad / JB;
     const long jb0 = nblk * blockIdx.y / A.nsplit, jb1 = nblk * (blockIdx.y + 1) / A.nsplit;
     const long len = jb1 - jb0;
     if (len <= 0) return;
-    long cur = ((long)blockIdx.x * (128 / JB)) % len;   // staggered start: neighbours in the grid walk different blocks
+    // Pass 1: every workgroup walks the blocks in the same order (a block is fetched from HBM once per
+    // XCD, then served from its L2).  Pass 2: staggered starts spread the union-find merges instead of
+    // piling every workgroup onto one block's roots at the same time.
+    long cur = MODE == 0 ? 0 : ((long)blockIdx.x * (CL_NW * 32 / JB)) % len;
 
     auto stage = [&](long jb, int buf) {
         float *dst = lds + buf * CL_BLK_FLOATS;
+        if (wave < 4) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int f = wave * 8 + q;
-            __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xp + (jb * 32 + f) * 256 + lane * 4),
-                                             (cl_lds_void *)(dst + f * 256), 16, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+                const int f = wave * 8 + q;
+                __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xp + (jb * 32 + f) * 256 + lane * 4),
+                                                 (cl_lds_void *)(dst + f * 256), 16, 0, 0);
+            }
         }
         // nh and (pass 2) parent of the block's JB points: waves 0/1 (2/3) move 64 dwords each
         if (wave * 64 < JB)
@@ -491,7 +500,7 @@ extern "C" size_t p2n_cluster_workspace_bytes(long N, int D, int min_samples) {
     int G, CT;
     cl_geometry(D, G, CT);
     ClWs w;
-    return cl_carve(w, nullptr, (N + 127) / 128 * 128, G, N, min_samples - 1);
+    return cl_carve(w, nullptr, (N + CL_NPAD_UNIT - 1) / CL_NPAD_UNIT * CL_NPAD_UNIT, G, N, min_samples - 1);
 }
 
 extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, void *stream_) {
@@ -513,9 +522,9 @@ static int cl_launch_pairs(int mode, const ClArgs &a, long nrowblk, hipStream_t 
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     if (mode == 0)
-        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 0>), dim3((unsigned)nrowblk, a.nsplit), dim3(256), ldsb, stream, a);
+        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 0>), dim3((unsigned)nrowblk, a.nsplit), dim3(CL_NW * 64), ldsb, stream, a);
     else
-        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 1>), dim3((unsigned)nrowblk, a.nsplit), dim3(256), ldsb, stream, a);
+        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 1>), dim3((unsigned)nrowblk, a.nsplit), dim3(CL_NW * 64), ldsb, stream, a);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
@@ -532,7 +541,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     P2N_REQUIRE(emb && labels && workspace, "p2n_cluster_embeddings: null pointer");
     int G, CT;
     cl_geometry(D, G, CT);
-    const long Npad = (N + 127) / 128 * 128;
+    const long Npad = (N + CL_NPAD_UNIT - 1) / CL_NPAD_UNIT * CL_NPAD_UNIT;
     const int cap = min_samples - 1;
     ClWs w;
     const size_t need = cl_carve(w, (char *)workspace, Npad, G, N, cap);
@@ -555,7 +564,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     a.tau = 2.5e-5f * (float)(G / 8);   // > 2 * (8G) * 2^-24 (dot of unit vectors) + norm and threshold roundings
     a.cnt = w.cnt; a.parent = w.parent; a.core = w.core; a.colblk_has_core = w.blk_has_core;
     a.nbr_cnt = w.nbr_cnt; a.nbr = w.nbr; a.cap = cap; a.stats = w.stats;
-    const long nrowblk = Npad / 128;
+    const long nrowblk = Npad / CL_ROWBLK;
     long ns = (2048 + nrowblk - 1) / nrowblk;            // enough workgroups to fill 256 CUs x 2 several times
     const long ncolblk = Npad / (CT * 32);
     a.nsplit = (int)(ns < 1 ? 1 : (ns > ncolblk ? ncolblk : ns));
@@ -593,7 +602,7 @@ extern "C" int p2n_cluster_counts(const void *workspace, long N, int D, int min_
     int G, CT;
     cl_geometry(D, G, CT);
     ClWs w;
-    cl_carve(w, (char *)workspace, (N + 127) / 128 * 128, G, N, min_samples - 1);
+    cl_carve(w, (char *)workspace, (N + CL_NPAD_UNIT - 1) / CL_NPAD_UNIT * CL_NPAD_UNIT, G, N, min_samples - 1);
     P2N_CHECK_HIP(hipMemcpyAsync(counts, w.cnt, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, (hipStream_t)stream_));
     return P2N_OK;
 }
@@ -609,7 +618,7 @@ extern "C" int p2n_cluster_stats(const void *workspace, long N, int D, int min_s
     int G, CT;
     cl_geometry(D, G, CT);
     ClWs w;
-    cl_carve(w, (char *)workspace, (N + 127) / 128 * 128, G, N, min_samples - 1);
+    cl_carve(w, (char *)workspace, (N + CL_NPAD_UNIT - 1) / CL_NPAD_UNIT * CL_NPAD_UNIT, G, N, min_samples - 1);
     P2N_CHECK_HIP(hipMemcpyAsync(stats, w.stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
     return P2N_OK;
 }

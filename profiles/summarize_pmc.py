@@ -11,7 +11,7 @@ import sys
 for d in sys.argv[1:]:
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f"{d}/pmc_counter_collection.csv")):
-        if r["Kernel_Name"].startswith(("p2n_", "void p2n_")):
+        if r["Kernel_Name"].startswith(("p2n_", "void p2n_", "cl_", "void cl_", "prep_")):
             acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(acc.items()):
         print(f"{k:45s} {c:12s} dispatches={len(v):3d} mean={sum(v)/len(v):14.3f}")
