@@ -26,16 +26,17 @@
 enum { LD_X = 0, LD_BNRELU = 1, LD_BNBWD = 2, LD_EMBGRAD = 3 };
 
 // ---------------------------------------------------------------- weight image
-// img[ct][G][lane][j] = M[32ct + (lane&31)][8G + 4(lane>>5) + j], M = W (rows=Cout) or
+// Fragment f = (kt*CT + ct)*4 + g  (k-tile major: the order the layer kernel consumes them):
+// img[f][lane][j] = M[32ct + (lane&31)][32kt + 8g + 4(lane>>5) + j], M = W (rows=Cout) or
 // W^T (rows=Cin); zero outside the real extent.
 __global__ void p2n_pack_w_kernel(const float *__restrict__ W, int ldw, int col0, int rows_real, int k_real, int trans,
-                                  float *__restrict__ img, int CT, int G) {
+                                  float *__restrict__ img, int CT, int KT) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)CT * G * 256) return;
+    if (i >= (long)CT * KT * 4 * 256) return;
     const int e = (int)(i & 255), lane = e >> 2, j = e & 3;
-    const long f = i >> 8;
-    const int ct = (int)(f / G), g = (int)(f % G);
-    const int row = 32 * ct + (lane & 31), k = 8 * g + 4 * (lane >> 5) + j;
+    const int f = (int)(i >> 8);
+    const int g = f & 3, ct = (f >> 2) % CT, kt = (f >> 2) / CT;
+    const int row = 32 * ct + (lane & 31), k = 32 * kt + 8 * g + 4 * (lane >> 5) + j;
     float v = 0.f;
     if (row < rows_real && k < k_real) v = trans ? W[(long)k * ldw + col0 + row] : W[(long)row * ldw + col0 + k];
     img[i] = v;
@@ -45,12 +46,12 @@ __global__ void p2n_pack_w_kernel(const float *__restrict__ W, int ldw, int col0
 struct LayerArgs {
     const float *in0;         // LD_X: x (P,F); LD_BNRELU: z_prev (K,Ppad); LD_BNBWD: da (K,Ppad); LD_EMBGRAD: gemb (P,E)
     const float *in1;         // LD_BNBWD: z (K,Ppad)
-    const float *wimg;        // [CT][G][64][4]
+    const float *wimg;        // [KT][CT][4][64][4]
     const float *bias;        // per output row, may be NULL
     const float *bias_cloud;  // [B][rows] added on top, may be NULL (layer 6: W6b.g)
     const float *tab;         // per-k constants: BNRELU {s,t}[K]; BNBWD {s,t,A1,A2,A3}[K]
     float *out;               // (rows,Ppad) channel-major, or (P,ldo) point-major when OUT_PM
-    int K, CT, rows, P, Ppad, N, ld;   // ld: F for LD_X, E for LD_EMBGRAD / OUT_PM
+    int K, KT, rows, P, Ppad, N, ld;   // KT = ceil(K/32); ld: F for LD_X, E for LD_EMBGRAD / OUT_PM
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -67,17 +68,76 @@ __device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *
     }
 }
 
-template <int MODE, int KT, bool OUT_PM>
+// Raw operand fetch of k-tile kt for this lane's point (no arithmetic: the loads are queued
+// before the MFMAs of the previous tile and consumed after them).
+template <int MODE>
+__device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bool valid, int h, f32x16 &r0, f32x16 &r1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int k0 = 32 * kt + 8 * g + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = valid && k0 + j < A.K;
+            if (MODE == LD_X || MODE == LD_EMBGRAD) {
+                r0[4 * g + j] = ok ? A.in0[pg * A.ld + k0 + j] : 0.f;
+            } else {
+                r0[4 * g + j] = ok ? A.in0[(long)(k0 + j) * A.Ppad + pg] : 0.f;
+                if (MODE == LD_BNBWD) r1[4 * g + j] = ok ? A.in1[(long)(k0 + j) * A.Ppad + pg] : 0.f;
+            }
+        }
+    }
+}
+
+// The fused elementwise work: BatchNorm+ReLU forward, or the whole BatchNorm/ReLU backward
+// dz = A1*dy + A2 + A3*z with dy = da masked by relu(bn(z)) > 0.  tab = per-k constants in LDS.
+template <int MODE>
+__device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool valid, int h, const float *tab, int KP,
+                                               const f32x16 &r0, const f32x16 &r1) {
+    if (MODE == LD_X || MODE == LD_EMBGRAD) return r0;
+    f32x16 out;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int k0 = 32 * kt + 8 * g + 4 * h;
+        const f32x4 s = *reinterpret_cast<const f32x4 *>(&tab[k0]);
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(&tab[KP + k0]);
+        f32x4 a1, a2, a3;
+        if (MODE == LD_BNBWD) {
+            a1 = *reinterpret_cast<const f32x4 *>(&tab[2 * KP + k0]);
+            a2 = *reinterpret_cast<const f32x4 *>(&tab[3 * KP + k0]);
+            a3 = *reinterpret_cast<const f32x4 *>(&tab[4 * KP + k0]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = 0.f;
+            if (valid && k0 + j < A.K) {
+                if (MODE == LD_BNRELU) {
+                    v = fmaxf(fmaf(r0[4 * g + j], s[j], t[j]), 0.f);
+                } else {
+                    const float z = r1[4 * g + j], da = r0[4 * g + j];
+                    const float dy = fmaf(z, s[j], t[j]) > 0.f ? da : 0.f;
+                    v = fmaf(a3[j], z, fmaf(a1[j], dy, a2[j]));
+                }
+            }
+            out[4 * g + j] = v;
+        }
+    }
+    return out;
+}
+
+// One wave = 32 points.  All CT output tiles are live accumulators; the reduction runs k-tile
+// by k-tile: while the CT*16 MFMAs of tile kt execute, the operands of tile kt+1 are already
+// in flight (fetched raw, transformed after the MFMAs), and the weights of the next chunk land
+// in the other LDS buffer by LDS-DMA (chunk = 32 fragments = 8/CT k-tiles).
+template <int MODE, int CT, bool OUT_PM>
 __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
-    // weights: two 32-fragment chunks in LDS, the next one landing by LDS-DMA while this one is
-    // consumed (same scheme as p2n_fwd.hip); a chunk holds 32/(4*KT) output tiles
     __shared__ __attribute__((aligned(16))) float wbuf[2 * TL_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float tab[5 * 256];
+    constexpr int KPC = 8 / CT;   // k-tiles per weight chunk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const long pg = ((long)blockIdx.x * 4 + wave) * 32 + p;
     const bool valid = pg < A.P;
-    constexpr int KP = KT * 32;   // padded reduction length
+    const int KT = A.KT, KP = KT * 32;
     tl_stage(A.wimg, wbuf, 0, wave, lane);   // first weight chunk flies while the operands load
     if (MODE == LD_BNRELU || MODE == LD_BNBWD) {
         const int nt = (MODE == LD_BNRELU ? 2 : 5);
@@ -85,80 +145,50 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
             const int which = i / KP, k = i - which * KP;
             tab[i] = k < A.K ? A.tab[which * A.K + k] : 0.f;
         }
-        __syncthreads();
     }
-    f32x16 in[KT];
+    f32x16 r0, r1;
+    tl_fetch<MODE>(A, 0, pg, valid, h, r0, r1);
+    f32x16 acc[CT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int k0 = 32 * kt + 8 * g + 4 * h;
-            if (MODE == LD_X) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    in[kt][4 * g + j] = (valid && k0 + j < A.K) ? A.in0[pg * A.ld + k0 + j] : 0.f;
-            } else if (MODE == LD_EMBGRAD) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    in[kt][4 * g + j] = (valid && k0 + j < A.K) ? A.in0[pg * A.ld + k0 + j] : 0.f;
-            } else if (MODE == LD_BNRELU) {
-                const f32x4 s = *reinterpret_cast<const f32x4 *>(&tab[k0]);
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(&tab[KP + k0]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = 0.f;
-                    if (valid && k0 + j < A.K) v = fmaxf(fmaf(A.in0[(long)(k0 + j) * A.Ppad + pg], s[j], t[j]), 0.f);
-                    in[kt][4 * g + j] = v;
-                }
-            } else {   // LD_BNBWD: dz = A1*dy + A2 + A3*z, dy = da masked by relu(bn(z)) > 0
-                const f32x4 s = *reinterpret_cast<const f32x4 *>(&tab[k0]);
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(&tab[KP + k0]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&tab[2 * KP + k0]);
-                const f32x4 a2 = *reinterpret_cast<const f32x4 *>(&tab[3 * KP + k0]);
-                const f32x4 a3 = *reinterpret_cast<const f32x4 *>(&tab[4 * KP + k0]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = 0.f;
-                    if (valid && k0 + j < A.K) {
-                        const float z = A.in1[(long)(k0 + j) * A.Ppad + pg];
-                        const float da = A.in0[(long)(k0 + j) * A.Ppad + pg];
-                        const float dy = fmaf(z, s[j], t[j]) > 0.f ? da : 0.f;
-                        v = fmaf(a3[j], z, fmaf(a1[j], dy, a2[j]));
-                    }
-                    in[kt][4 * g + j] = v;
-                }
-            }
-        }
-    const int cloud = valid ? (int)(pg / A.N) : 0;
-    constexpr int TPC = 32 / (4 * KT);   // output tiles per weight chunk
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+    __syncthreads();   // tab visible (and chunk 0 landed)
+    f32x16 cur = tl_transform<MODE>(A, 0, valid, h, tab, KP, r0, r1);
 #pragma unroll 1
-    for (int ct = 0; ct < A.CT; ++ct) {
-        if (ct % TPC == 0) {
-            __syncthreads();   // chunk ct/TPC has landed (vmcnt(0) + barrier); the other buffer is free
-            tl_stage(A.wimg, wbuf, ct / TPC + 1, wave, lane);
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt % KPC == 0) {
+            if (kt) __syncthreads();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
+            tl_stage(A.wimg, wbuf, kt / KPC + 1, wave, lane);
         }
-        const float *wb = wbuf + ((ct / TPC) & 1) * TL_CHUNK_FLOATS + (ct % TPC) * (KT * 4 * 256) + lane * 4;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(wb + (kt * 4 + g) * 256);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], in[kt][4 * g + j], acc);
-            }
+        if (kt + 1 < KT) tl_fetch<MODE>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
+        const float *wb = wbuf + ((kt / KPC) & 1) * TL_CHUNK_FLOATS + (kt % KPC) * (CT * 4 * 256) + lane * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int r0 = 32 * ct + 8 * g + 4 * h;
+            f32x4 w[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const f32x4 *>(wb + (ct * 4 + g) * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA32(w[ct][j], cur[4 * g + j], acc[ct]);
+        }
+        if (kt + 1 < KT) cur = tl_transform<MODE>(A, kt + 1, valid, h, tab, KP, r0, r1);
+    }
+    const int cloud = valid ? (int)(pg / A.N) : 0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        if (32 * ct >= A.rows) break;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r0i = 32 * ct + 8 * g + 4 * h;
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = acc[4 * g + j];
-                if (r0 + j < A.rows) {
-                    if (A.bias) v += A.bias[r0 + j];
-                    if (A.bias_cloud) v += A.bias_cloud[(long)cloud * A.rows + r0 + j];
+                float v = acc[ct][4 * g + j];
+                if (r0i + j < A.rows) {
+                    if (A.bias) v += A.bias[r0i + j];
+                    if (A.bias_cloud) v += A.bias_cloud[(long)cloud * A.rows + r0i + j];
                 }
                 o[j] = v;
             }
@@ -166,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
                 if (valid)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (r0 + j < A.rows) A.out[pg * A.ld + r0 + j] = o[j];
+                        if (r0i + j < A.rows) A.out[pg * A.ld + r0i + j] = o[j];
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (r0 + j < A.rows) A.out[(long)(r0 + j) * A.Ppad + pg] = o[j];   // pad columns too (finite)
+                    if (r0i + j < A.rows) A.out[(long)(r0i + j) * A.Ppad + pg] = o[j];   // pad columns too (finite)
             }
         }
     }
@@ -523,21 +553,26 @@ void bind_params(Net &n, const void *const *ptrs) {
     }
 }
 
-int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float *img, int CT, int KT, hipStream_t s) {
+int ct_pad(int rows) {   // output tiles rounded up to a power of two (the kernel's chunk arithmetic needs 8 % CT == 0)
+    const int ct = (rows + 31) / 32;
+    return ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
+}
+
+int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float *img, hipStream_t s) {
+    const int CT = ct_pad(rows), KT = (k + 31) / 32;
     const long n = (long)CT * KT * 4 * 256;
     hipLaunchKernelGGL(p2n_pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, col0, rows, k, trans,
-                       img, CT, KT * 4);
+                       img, CT, KT);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
 
-int kt_for(int k) { return k <= 32 ? 1 : k <= 64 ? 2 : k <= 128 ? 4 : 8; }
-
 template <int MODE, bool PM>
-int launch_layer(const LayerArgs &a, int KT, hipStream_t s) {
+int launch_layer(LayerArgs a, hipStream_t s) {
     const dim3 grid(a.Ppad / 128), blk(256);
+    a.KT = (a.K + 31) / 32;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_GEMM, s);
-    switch (KT) {
+    switch (ct_pad(a.rows)) {
         case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM>), grid, blk, 0, s, a); break;
         case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM>), grid, blk, 0, s, a); break;
         case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM>), grid, blk, 0, s, a); break;
@@ -610,18 +645,16 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
     hipStream_t s = (hipStream_t)stream_;
     for (int l = 0; l < 9; ++l) {
         const int K = (l == 6) ? 256 : n.cin[l];
-        const int KT = (l == 0) ? 1 : kt_for(K);
-        const int CT = (n.cout[l] + 31) / 32;
-        TRY(pack_w(n.W[l], n.cin[l], 0, n.cout[l], K, 0, n.wimg, CT, KT, s));
+        TRY(pack_w(n.W[l], n.cin[l], 0, n.cout[l], K, 0, n.wimg, s));
         LayerArgs a = {};
-        a.wimg = n.wimg; a.bias = n.b[l]; a.K = K; a.CT = CT; a.rows = n.cout[l];
+        a.wimg = n.wimg; a.bias = n.b[l]; a.K = K; a.rows = n.cout[l];
         a.P = n.P; a.Ppad = n.Ppad; a.N = n.N;
-        if (l == 0) { a.in0 = x; a.ld = F; a.out = n.z[0]; TRY((launch_layer<LD_X, false>(a, 1, s))); }
+        if (l == 0) { a.in0 = x; a.ld = F; a.out = n.z[0]; TRY((launch_layer<LD_X, false>(a, s))); }
         else {
             a.in0 = n.z[l - 1]; a.tab = n.ftab[l - 1];
             if (l == 6) a.bias_cloud = n.bias6c;
-            if (l == 8) { a.out = emb; a.ld = E; TRY((launch_layer<LD_BNRELU, true>(a, KT, s))); }
-            else { a.out = n.z[l]; TRY((launch_layer<LD_BNRELU, false>(a, KT, s))); }
+            if (l == 8) { a.out = emb; a.ld = E; TRY((launch_layer<LD_BNRELU, true>(a, s))); }
+            else { a.out = n.z[l]; TRY((launch_layer<LD_BNRELU, false>(a, s))); }
         }
         if (l == 8) break;
         StatArgs st = {};
@@ -680,12 +713,11 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
         w.a0 = gemb; w.ld_a = E; w.b0 = n.z[7]; w.btab = n.ftab[7]; w.dW = dW[8];
         w.rows = E; w.cols = 128; w.ldw = 128; w.P = n.P; w.Ppad = n.Ppad;
         TRY((launch_wgrad<LD_EMBGRAD, LD_BNRELU>(w, s)));
-        const int KT = kt_for(E);
-        TRY(pack_w(n.W[8], 128, 0, 128, E, 1, n.wimg, 4, KT, s));
+        TRY(pack_w(n.W[8], 128, 0, 128, E, 1, n.wimg, s));
         LayerArgs a = {};
-        a.in0 = gemb; a.ld = E; a.wimg = n.wimg; a.K = E; a.CT = 4; a.rows = 128;
+        a.in0 = gemb; a.ld = E; a.wimg = n.wimg; a.K = E; a.rows = 128;
         a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[0];
-        TRY((launch_layer<LD_EMBGRAD, false>(a, KT, s)));
+        TRY((launch_layer<LD_EMBGRAD, false>(a, s)));
     }
     int cur = 0;   // n.da[cur] holds da_l for the layer being processed
     for (int l = 7; l >= 0; --l) {
@@ -721,12 +753,11 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
         if (l == 0) break;
         // data gradient: da_{l-1} = W_l^T . dz_l
         const int rows = (l == 6) ? 256 : n.cin[l];
-        const int KT = kt_for(C);
-        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, rows / 32, KT, s));
+        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, s));
         LayerArgs a = {};
-        a.in0 = n.da[cur]; a.in1 = n.z[l]; a.tab = n.btab; a.wimg = n.wimg; a.K = C; a.CT = rows / 32; a.rows = rows;
+        a.in0 = n.da[cur]; a.in1 = n.z[l]; a.tab = n.btab; a.wimg = n.wimg; a.K = C; a.rows = rows;
         a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[cur ^ 1];
-        TRY((launch_layer<LD_BNBWD, false>(a, KT, s)));
+        TRY((launch_layer<LD_BNBWD, false>(a, s)));
         cur ^= 1;
         if (l == 6) {
             hipLaunchKernelGGL(p2n_maxpool_bwd_kernel, dim3((256 * B + 255) / 256), dim3(256), 0, s, n.da[cur], n.Ppad, N,
