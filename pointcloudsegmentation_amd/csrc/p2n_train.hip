@@ -349,26 +349,39 @@ __global__ __launch_bounds__(256) void p2n_row_stats_kernel(StatArgs A) {
     }
     const float *z = A.z + (long)row * A.Ppad;
     const float *da = A.da ? A.da + (long)row * A.Ppad : nullptr;
-    float u = 0.f, v = 0.f;
-    if (MODE == ST_FWD) {
-        const float pivot = z[0];
-        for (long p = p0 + threadIdx.x; p < p1; p += 256) { const float d = z[p] - pivot; u += d; v = fmaf(d, d, v); }
-    } else if (MODE == ST_BWD) {
-        const float sc = A.tab[row], sf = A.tab[A.rows + row], mean = A.tab[2 * A.rows + row], rstd = A.tab[3 * A.rows + row];
-        for (long p = p0 + threadIdx.x; p < p1; p += 256) {
-            const float zz = z[p];
-            const float dy = fmaf(zz, sc, sf) > 0.f ? da[p] : 0.f;
-            u += dy; v = fmaf(dy, (zz - mean) * rstd, v);
-        }
-    } else {
-        const float sc = A.tab[row], sf = A.tab[A.rows + row], a1 = A.tab[2 * A.rows + row],
-                    a2 = A.tab[3 * A.rows + row], a3 = A.tab[4 * A.rows + row];
-        for (long p = p0 + threadIdx.x; p < p1; p += 256) {
-            const float zz = z[p];
-            const float dy = fmaf(zz, sc, sf) > 0.f ? da[p] : 0.f;
-            u += fmaf(a3, zz, fmaf(a1, dy, a2));
-        }
+    float sc = 0.f, sf = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, pivot = 0.f;
+    if (MODE == ST_FWD) pivot = z[0];
+    else {
+        sc = A.tab[row]; sf = A.tab[A.rows + row]; c2 = A.tab[2 * A.rows + row]; c3 = A.tab[3 * A.rows + row];
+        if (MODE == ST_DZCLOUD) c4 = A.tab[4 * A.rows + row];
     }
+    // per-thread sums in double: these sums cancel heavily (sum dy ~ 0) and feed eight chained
+    // BatchNorm backward stages; the kernel is bandwidth-bound, the fp64 adds are free
+    double ud = 0.0, vd = 0.0;
+    auto one = [&](float zz, float dd) __attribute__((always_inline)) {
+        if (MODE == ST_FWD) {
+            const float d = zz - pivot; ud += (double)d; vd += (double)d * (double)d;
+        } else if (MODE == ST_BWD) {   // c2 = mean, c3 = rstd
+            const float dy = fmaf(zz, sc, sf) > 0.f ? dd : 0.f;
+            ud += (double)dy; vd += (double)(dy * ((zz - c2) * c3));
+        } else {                        // c2,c3,c4 = A1,A2,A3
+            const float dy = fmaf(zz, sc, sf) > 0.f ? dd : 0.f;
+            ud += (double)fmaf(c4, zz, fmaf(c2, dy, c3));
+        }
+    };
+    // 16-byte loads over the aligned middle of [p0,p1), scalar head and tail (rows start 512-byte aligned)
+    long q0 = (p0 + 3) & ~3L, q1 = p1 & ~3L;
+    if (q0 > q1) { q0 = p1; q1 = p1; }
+    for (long p = p0 + threadIdx.x; p < q0; p += 256) one(z[p], MODE == ST_FWD ? 0.f : da[p]);
+    for (long p = q0 + 4L * threadIdx.x; p < q1; p += 1024) {
+        const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + p);
+        f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+        if (MODE != ST_FWD) dd = *reinterpret_cast<const f32x4 *>(da + p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) one(zz[j], dd[j]);
+    }
+    for (long p = q1 + threadIdx.x; p < p1; p += 256) one(z[p], MODE == ST_FWD ? 0.f : da[p]);
+    float u = (float)ud, v = (float)vd;
     u = block_sum_256(u, sh);
     if (MODE != ST_DZCLOUD) v = block_sum_256(v, sh);
     if (threadIdx.x == 0) {
@@ -515,7 +528,7 @@ struct Net {
     size_t total;
 };
 
-constexpr int STAT_S = 64;
+constexpr int STAT_S = 16;
 
 size_t carve(Net &n, char *base) {
     size_t off = 0;
