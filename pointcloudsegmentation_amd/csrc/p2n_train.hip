@@ -228,10 +228,44 @@ struct WgArgs {
 #define WG_PTS 64
 #define WG_LD (WG_PTS + 4)
 
+// One thread's share of a 64-row x 64-point operand block, split in two so the global loads can
+// be queued before the MFMAs of the previous step and the transform + LDS store run after them.
 template <int MODE>
-__device__ __forceinline__ void wgrad_load_block(float *__restrict__ dst, const float *__restrict__ s0,
-                                                 const float *__restrict__ s1, const float *__restrict__ tab,
-                                                 int row0, int nrows, int ntab, long p0, long pend, int Ppad, int ld) {
+struct WgStage {
+    f32x4 v0[4], v1[4];
+};
+
+template <int MODE>
+__device__ __forceinline__ void wgrad_fetch(WgStage<MODE> &st, const float *__restrict__ s0, const float *__restrict__ s1,
+                                            int row0, int nrows, long p0, long pend, int Ppad, int ld) {
+    const int t = threadIdx.x;
+    if (MODE == LD_BNBWD || MODE == LD_BNRELU) {
+        const int seg = (t & 3) * 16;
+        const int row = row0 + (t >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long p = p0 + seg + 4 * i;
+            st.v0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            st.v1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < nrows && p < pend) {   // slices start at multiples of 64 and Ppad is a multiple of 128: in-row loads
+                st.v0[i] = *reinterpret_cast<const f32x4 *>(s0 + (long)row * Ppad + p);
+                if (MODE == LD_BNBWD) st.v1[i] = *reinterpret_cast<const f32x4 *>(s1 + (long)row * Ppad + p);
+            }
+        }
+    } else {   // point-major sources: gemb (P,E) or x (P,F)
+        const int seg = (t >> 6) * 16;
+        const int row = row0 + (t & 63);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long p = p0 + seg + i;
+            st.v0[i >> 2][i & 3] = (row < nrows && p < pend) ? s0[p * ld + row] : 0.f;
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__restrict__ dst, const float *__restrict__ tab,
+                                           int row0, int nrows, int ntab, long p0, long pend) {
     const int t = threadIdx.x;
     if (MODE == LD_BNBWD || MODE == LD_BNRELU) {
         const int r = t >> 2, seg = (t & 3) * 16;
@@ -246,36 +280,32 @@ __device__ __forceinline__ void wgrad_load_block(float *__restrict__ dst, const 
         for (int i = 0; i < 4; ++i) {
             const long p = p0 + seg + 4 * i;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            if (rok && p < pend) {   // slices start at multiples of 64 and Ppad is a multiple of 128: in-row loads
-                const f32x4 z = *reinterpret_cast<const f32x4 *>((MODE == LD_BNBWD ? s1 : s0) + (long)row * Ppad + p);
-                if (MODE == LD_BNBWD) {
-                    const f32x4 da = *reinterpret_cast<const f32x4 *>(s0 + (long)row * Ppad + p);
+            if (rok && p < pend) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float dy = fmaf(z[j], c0, c1) > 0.f ? da[j] : 0.f;
-                        o[j] = (p + j < pend) ? fmaf(c4, z[j], fmaf(c2, dy, c3)) : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    if (MODE == LD_BNBWD) {
+                        const float z = st.v1[i][j];
+                        const float dy = fmaf(z, c0, c1) > 0.f ? st.v0[i][j] : 0.f;
+                        o[j] = (p + j < pend) ? fmaf(c4, z, fmaf(c2, dy, c3)) : 0.f;
+                    } else {
+                        o[j] = (p + j < pend) ? fmaxf(fmaf(st.v0[i][j], c0, c1), 0.f) : 0.f;
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (p + j < pend) ? fmaxf(fmaf(z[j], c0, c1), 0.f) : 0.f;
                 }
             }
             *reinterpret_cast<f32x4 *>(dst + r * WG_LD + seg + 4 * i) = o;
         }
-    } else {   // point-major sources: gemb (P,E) or x (P,F)
+    } else {
         const int r = t & 63, seg = (t >> 6) * 16;
-        const int row = row0 + r;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const long p = p0 + seg + i;
-            dst[r * WG_LD + seg + i] = (row < nrows && p < pend) ? s0[p * ld + row] : 0.f;
-        }
+        for (int i = 0; i < 16; ++i) dst[r * WG_LD + seg + i] = st.v0[i >> 2][i & 3];
     }
 }
 
-template <int AMODE, int BMODE>
+// RT x CT MFMA tiles per wave: the workgroup's block of dW is (64 RT) x (64 CT).  128 x 128 blocks
+// halve the operand re-reads of the big layers (the 64 x 64 version was bound by L2/HBM traffic).
+template <int AMODE, int BMODE, int RT, int CT>
 __global__ __launch_bounds__(256) void p2n_wgrad_kernel(WgArgs A) {
-    __shared__ __attribute__((aligned(16))) float sa[WG_TILE * WG_LD], sb[WG_TILE * WG_LD];
+    __shared__ __attribute__((aligned(16))) float sa[RT * WG_TILE * WG_LD], sb[CT * WG_TILE * WG_LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
@@ -283,35 +313,75 @@ __global__ __launch_bounds__(256) void p2n_wgrad_kernel(WgArgs A) {
     const long s0 = (long)blockIdx.x * A.slice;
     long s1 = s0 + A.slice;
     if (s1 > A.P) s1 = A.P;
-    f32x16 acc;
+    f32x16 acc[RT][CT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int k = 0; k < CT; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][k][e] = 0.f;
+    WgStage<AMODE> sta[RT];
+    WgStage<BMODE> stb[CT];
+    auto fetch = [&](long p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) wgrad_fetch<AMODE>(sta[i], A.a0, A.a1, (br * RT + i) * WG_TILE, A.rows, p0, s1, A.Ppad, A.ld_a);
+#pragma unroll
+        for (int k = 0; k < CT; ++k) wgrad_fetch<BMODE>(stb[k], A.b0, nullptr, (bc * CT + k) * WG_TILE, A.cols, p0, s1, A.Ppad, A.ld_b);
+    };
+    auto park = [&](long p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+            wgrad_park<AMODE>(sta[i], sa + i * WG_TILE * WG_LD, A.atab, (br * RT + i) * WG_TILE, A.rows, A.rows, p0, s1);
+#pragma unroll
+        for (int k = 0; k < CT; ++k)
+            wgrad_park<BMODE>(stb[k], sb + k * WG_TILE * WG_LD, A.btab, (bc * CT + k) * WG_TILE, A.cols, A.cols, p0, s1);
+    };
+    if (s0 < s1) {
+        fetch(s0);
+        park(s0);
+    }
+    // wave (wr, wc) owns tiles [wr*RT + i][wc*CT + k] of the block's (2 RT) x (2 CT) tile grid
+    const float *pa = sa + (32 * wr * RT + r) * WG_LD + 4 * h;
+    const float *pb = sb + (32 * wc * CT + r) * WG_LD + 4 * h;
     for (long p0 = s0; p0 < s1; p0 += WG_PTS) {
-        __syncthreads();
-        wgrad_load_block<AMODE>(sa, A.a0, A.a1, A.atab, br * WG_TILE, A.rows, A.rows, p0, s1, A.Ppad, A.ld_a);
-        wgrad_load_block<BMODE>(sb, A.b0, nullptr, A.btab, bc * WG_TILE, A.cols, A.cols, p0, s1, A.Ppad, A.ld_b);
-        __syncthreads();
-        const float *pa = sa + (32 * wr + r) * WG_LD + 4 * h;
-        const float *pb = sb + (32 * wc + r) * WG_LD + 4 * h;
+        __syncthreads();   // the block of step p0 is in LDS
+        const bool more = p0 + WG_PTS < s1;
+        if (more) fetch(p0 + WG_PTS);   // in flight while the MFMAs run
 #pragma unroll
         for (int G = 0; G < WG_PTS / 8; ++G) {
-            const f32x4 av = *reinterpret_cast<const f32x4 *>(pa + 8 * G);
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(pb + 8 * G);
+            f32x4 av[RT], bv[CT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
+            for (int i = 0; i < RT; ++i) av[i] = *reinterpret_cast<const f32x4 *>(pa + i * 32 * WG_LD + 8 * G);
+#pragma unroll
+            for (int k = 0; k < CT; ++k) bv[k] = *reinterpret_cast<const f32x4 *>(pb + k * 32 * WG_LD + 8 * G);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int k = 0; k < CT; ++k) acc[i][k] = MFMA32(av[i][j], bv[k][j], acc[i][k]);
+        }
+        if (more) {
+            __syncthreads();   // everybody has read this step's block
+            park(p0 + WG_PTS);
         }
     }
     if (s0 >= s1) return;
     // D: column = lane&31 (input channel), rows = 8g+4h+j (output channel)
-    const int oc = bc * WG_TILE + 32 * wc + r;
-    if (oc < A.cols)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int orow = br * WG_TILE + 32 * wr + 8 * g + 4 * h + j;
-                if (orow < A.rows) atomicAdd(&A.dW[(long)orow * A.ldw + oc], acc[4 * g + j]);
-            }
+        for (int k = 0; k < CT; ++k) {
+            const int oc = bc * CT * WG_TILE + 32 * (wc * CT + k) + r;
+            if (oc >= A.cols) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int orow = br * RT * WG_TILE + 32 * (wr * RT + i) + 8 * g + 4 * h + j;
+                    if (orow < A.rows) atomicAdd(&A.dW[(long)orow * A.ldw + oc], acc[i][k][4 * g + j]);
+                }
+        }
 }
 
 // ---------------------------------------------------------------- row statistics
@@ -597,8 +667,8 @@ int launch_layer(LayerArgs a, hipStream_t s) {
 }
 
 int wgrad_slice(int P, int blocks) {
-    // aim at ~1024 workgroups in flight; slices are multiples of 64 points
-    long want = 1024 / (blocks > 0 ? blocks : 1);
+    // aim at ~512 workgroups (two rounds of one per CU): every workgroup ends with a block of atomics; slices are multiples of 64 points
+    long want = 512 / (blocks > 0 ? blocks : 1);
     if (want < 1) want = 1;
     long sl = (P + want - 1) / want;
     sl = (sl + 63) / 64 * 64;
@@ -606,17 +676,26 @@ int wgrad_slice(int P, int blocks) {
     return (int)sl;
 }
 
-template <int AM, int BM>
-int launch_wgrad(WgArgs a, hipStream_t s) {
-    const int ntr = (a.rows + 63) / 64;
-    a.ntc = (a.cols + 63) / 64;
+template <int AM, int BM, int RT, int CT>
+int launch_wgrad_rc(WgArgs a, hipStream_t s) {
+    const int ntr = (a.rows + 64 * RT - 1) / (64 * RT);
+    a.ntc = (a.cols + 64 * CT - 1) / (64 * CT);
     a.slice = wgrad_slice(a.P, ntr * a.ntc);
     const long nsl = ((long)a.P + a.slice - 1) / a.slice;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_WGRAD, s);
-    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM>), dim3((unsigned)nsl, ntr * a.ntc), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM, RT, CT>), dim3((unsigned)nsl, ntr * a.ntc), dim3(256), 0, s, a);
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
+}
+
+template <int AM, int BM>
+int launch_wgrad(WgArgs a, hipStream_t s) {
+    const bool r2 = a.rows >= 128, c2 = a.cols >= 128;
+    if (r2 && c2) return launch_wgrad_rc<AM, BM, 2, 2>(a, s);
+    if (r2) return launch_wgrad_rc<AM, BM, 2, 1>(a, s);
+    if (c2) return launch_wgrad_rc<AM, BM, 1, 2>(a, s);
+    return launch_wgrad_rc<AM, BM, 1, 1>(a, s);
 }
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
