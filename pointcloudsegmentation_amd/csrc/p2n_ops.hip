@@ -315,8 +315,10 @@ extern "C" int p2n_ball_query(const float *xyz, const float *new_xyz, int B, int
     if (B == 0 || M == 0) return P2N_OK;
     P2N_REQUIRE(xyz && new_xyz && idx, "p2n_ball_query: null pointer");
     P2N_REQUIRE(B <= 65535, "p2n_ball_query: B > 65535");
+    const int ps = p2n_prof_begin(P2N_K_BALL, (hipStream_t)stream);
     hipLaunchKernelGGL(p2n_ball_query_kernel, dim3((M + BQ_THREADS - 1) / BQ_THREADS, B), dim3(BQ_THREADS), 0,
                        (hipStream_t)stream, xyz, new_xyz, N, M, radius * radius, nsample, idx);
+    p2n_prof_end(ps, (hipStream_t)stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
@@ -452,6 +454,34 @@ __global__ __launch_bounds__(256) void p2n_group_gather_kernel(const float *__re
         if (c0 + c < C) out[((long)b * C + c0 + c) * MS + j] = feat[((long)b * C + c0 + c) * N + i];
 }
 
+// Four output columns per thread: one 16-byte index load, GG_CH x 4 independent gathers in flight,
+// GG_CH 16-byte stores (the output is 88 % of the traffic).  Needs MS % 4 == 0 and 16-byte-aligned
+// idx / out (the launcher checks; otherwise the scalar kernel above runs).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void p2n_group_gather_v4_kernel(const float *__restrict__ feat,
+                                                                 const int32_t *__restrict__ idx, int C, int N, long MS,
+                                                                 float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long j = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= MS) return;
+    const i32x4 iv = *reinterpret_cast<const i32x4 *>(idx + (long)b * MS + j);
+    int i[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) i[q] = clamp_idx(iv[q], N);
+    const int c0 = blockIdx.y * GG_CH;
+    f32x4 v[GG_CH];
+#pragma unroll
+    for (int c = 0; c < GG_CH; ++c)
+        if (c0 + c < C) {
+            const float *f = feat + ((long)b * C + c0 + c) * N;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[c][q] = f[i[q]];
+        }
+#pragma unroll
+    for (int c = 0; c < GG_CH; ++c)
+        if (c0 + c < C) __builtin_nontemporal_store(v[c], reinterpret_cast<f32x4 *>(out + ((long)b * C + c0 + c) * MS + j));
+}
+
 __global__ __launch_bounds__(256) void p2n_group_gather_bwd_kernel(const float *__restrict__ gout,
                                                                   const int32_t *__restrict__ idx, int C, int N,
                                                                   long MS, float *__restrict__ gfeat) {
@@ -512,8 +542,14 @@ extern "C" int p2n_group_gather(const float *feat, const int32_t *idx, int B, in
     if (B == 0 || C == 0 || MS == 0) return P2N_OK;
     P2N_REQUIRE(feat && idx && out, "p2n_group_gather: null pointer");
     P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_group_gather: B or C too large");
-    hipLaunchKernelGGL(p2n_group_gather_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
-                       dim3(256), 0, (hipStream_t)stream, feat, idx, C, N, MS, out);
+    const int ps = p2n_prof_begin(P2N_K_GATHER, (hipStream_t)stream);
+    if (MS % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(p2n_group_gather_v4_kernel, dim3((unsigned)((MS / 4 + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
+                           dim3(256), 0, (hipStream_t)stream, feat, idx, C, N, MS, out);
+    else
+        hipLaunchKernelGGL(p2n_group_gather_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
+                           dim3(256), 0, (hipStream_t)stream, feat, idx, C, N, MS, out);
+    p2n_prof_end(ps, (hipStream_t)stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
@@ -555,6 +591,38 @@ __global__ __launch_bounds__(256) void p2n_three_interp_kernel(const float *__re
         }
 }
 
+// Four unknown points per thread (n % 4 == 0, 16-byte-aligned idx / weight / out): 3 + 3 16-byte
+// loads for the neighbour table, GG_CH x 12 gathers, GG_CH 16-byte stores.  Same arithmetic order.
+__global__ __launch_bounds__(256) void p2n_three_interp_v4_kernel(const float *__restrict__ feat,
+                                                                 const int32_t *__restrict__ idx,
+                                                                 const float *__restrict__ w, int C, int m, int n,
+                                                                 float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    int id[12];
+    float ww[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const i32x4 iv = *reinterpret_cast<const i32x4 *>(idx + ((long)b * n + i) * 3 + 4 * q);
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + ((long)b * n + i) * 3 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { id[4 * q + e] = clamp_idx(iv[e], m); ww[4 * q + e] = wv[e]; }
+    }
+    const int c0 = blockIdx.y * GG_CH;
+#pragma unroll
+    for (int c = 0; c < GG_CH; ++c)
+        if (c0 + c < C) {
+            const float *f = feat + ((long)b * C + c0 + c) * m;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = __fadd_rn(__fadd_rn(__fmul_rn(ww[3 * e], f[id[3 * e]]), __fmul_rn(ww[3 * e + 1], f[id[3 * e + 1]])),
+                                 __fmul_rn(ww[3 * e + 2], f[id[3 * e + 2]]));
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(out + ((long)b * C + c0 + c) * n + i));
+        }
+}
+
 __global__ __launch_bounds__(256) void p2n_three_interp_bwd_kernel(const float *__restrict__ gout,
                                                                   const int32_t *__restrict__ idx,
                                                                   const float *__restrict__ w, int C, int m, int n,
@@ -584,8 +652,14 @@ extern "C" int p2n_three_interpolate(const float *feat, const int32_t *idx, cons
     if (B == 0 || C == 0 || n == 0) return P2N_OK;
     P2N_REQUIRE(feat && idx && weight && out, "p2n_three_interpolate: null pointer");
     P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_three_interpolate: B or C too large");
-    hipLaunchKernelGGL(p2n_three_interp_kernel, dim3((n + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
-                       (hipStream_t)stream, feat, idx, weight, C, m, n, out);
+    const int ps = p2n_prof_begin(P2N_K_INTERP, (hipStream_t)stream);
+    if (n % 4 == 0 && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(p2n_three_interp_v4_kernel, dim3((n / 4 + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
+                           (hipStream_t)stream, feat, idx, weight, C, m, n, out);
+    else
+        hipLaunchKernelGGL(p2n_three_interp_kernel, dim3((n + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
+                           (hipStream_t)stream, feat, idx, weight, C, m, n, out);
+    p2n_prof_end(ps, (hipStream_t)stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
