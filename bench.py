@@ -113,6 +113,36 @@ def fps_leg(device):
             "status": ops.fps_status(device)}
 
 
+def bf16_leg(model, x, lib, steps):
+    """The same step on the opt-in bf16 MFMA path (north_star: 'bf16/fp32 MFMA GEMMs', 2e-2 parity):
+    reported beside the headline, never as it -- the reference computes in fp32."""
+    with torch.no_grad():
+        ref = model(x)
+        model.precision = "bf16"
+        try:
+            for _ in range(3):
+                y = model(x)
+            torch.cuda.synchronize()
+            lib.p2n_profile_enable(1)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = model(x)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            k = collect_kernel_ms()
+            lib.p2n_profile_enable(0)
+        finally:
+            model.precision = "fp32"
+    pts = x.shape[0] * x.shape[1]
+    dev = float((y - ref).abs().max() / ref.abs().max())
+    # algorithmic HBM bytes per point: x 24 + bf16 f3 image 512 written + 512 read + emb 256
+    bytes_pt = 24 + 512 + 512 + 256
+    return {"value": pts * steps / dt, "unit": "points/s", "ms_per_step": 1e3 * dt / steps, "dtype": "bf16 (fp32 accumulate)",
+            "kernels_ms": {n: v[0] for n, v in k.items() if v[1]}, "max_dev_vs_fp32_path": dev,
+            "hbm_algorithmic_GB_per_s": bytes_pt * pts * steps / dt / 1e9,
+            "note": "opt-in path (model.precision = 'bf16'); layers 0-2 split bf16, layers 3-8 bf16, epilogues fp32"}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of this workload's kernel, from the committed PMC summary (counters
     cannot be read from inside the process); None when the file is absent."""
@@ -207,6 +237,7 @@ def main():
                                  "(profiles/pmc_traffic.json), not collected live"},
         }
         if world == 1:
+            out["bf16"] = bf16_leg(model, x, lib, args.steps)
             if not args.no_fps:
                 out["fps"] = fps_leg(device)
             if not args.no_cpu:

@@ -64,6 +64,19 @@ int p2n_forward_eval(const float *x, int B, int N, int feature_dim, int embeddin
                      float *f1, float *f2, float *f3,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- eval forward in bf16 (opt-in) -------------------------------------------
+ * Same contract as p2n_forward_eval (inputs and outputs stay float32) computed on bf16 MFMA
+ * with fp32 accumulation (BASELINE north_star: "bf16/fp32 MFMA GEMMs", 2e-2 relative).  Layers 0-2
+ * run in split bf16 (hi + lo) to keep the coordinates' precision; measured deviation from the
+ * fp32 path: ~6e-3 of max|emb|.  Its packed image is built by p2n_pack_eval_params_bf16
+ * (p2n_packed_param_count_bf16 floats); the workspace size is p2n_forward_eval_workspace_bytes. */
+long p2n_packed_param_count_bf16(int feature_dim, int embedding_dim);
+int p2n_pack_eval_params_bf16(const float *raw, int feature_dim, int embedding_dim, float *packed, void *stream);
+int p2n_forward_eval_bf16(const float *x, int B, int N, int feature_dim, int embedding_dim,
+                          const float *packed, float *emb, float *global_f,
+                          float *f1, float *f2, float *f3,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- training path -------------------------------------------------------
  * Train-mode forward (reference point2net.py:36-48,67-87 with model.train(),
  * reference train.py:109,124): BatchNorm uses batch statistics (biased variance),

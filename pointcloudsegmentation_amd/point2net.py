@@ -32,7 +32,8 @@ class _PackedCache:
         self.key = None
         self.packed = None
 
-    def get(self, module: nn.Module, feature_dim: int, embedding_dim: int, prefix: str = "") -> torch.Tensor:
+    def get(self, module: nn.Module, feature_dim: int, embedding_dim: int, prefix: str = "",
+            precision: str = "fp32") -> torch.Tensor:
         """prefix="" : module is a Point2Net.  prefix="encoder.": module is a bare
         PointNet2Encoder; the head slots of the image are zero-filled (never read:
         the head kernel is skipped when no embedding is requested)."""
@@ -42,14 +43,14 @@ class _PackedCache:
         if prefix:
             order = [k[len(prefix):] for k in order if k.startswith(prefix)]
         tensors = [sd[k] for k in order]
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        key = (precision,) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key != self.key:
             parts = [t.detach().reshape(-1).to(torch.float32) for t in tensors]
             have = sum(p.numel() for p in parts)
             need = _params.param_count(feature_dim, embedding_dim)
             if have < need:
                 parts.append(torch.zeros(need - have, dtype=torch.float32, device=parts[0].device))
-            self.packed = _rt.pack_eval_params(torch.cat(parts), feature_dim, embedding_dim)
+            self.packed = _rt.pack_eval_params(torch.cat(parts), feature_dim, embedding_dim, precision)
             self.key = key
         return self.packed
 
@@ -63,6 +64,7 @@ class PointNet2Encoder(nn.Module):
         self.mlp2 = _mlp(64, 128, 128)
         self.mlp3 = _mlp(128, 256, 256)
         self.in_channels = in_channels
+        self.precision = "fp32"   # "bf16": opt-in bf16 MFMA eval path (GPU tensors only)
         self._cache = _PackedCache()
 
     def forward(self, x):
@@ -71,8 +73,9 @@ class PointNet2Encoder(nn.Module):
                                  (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
                 from .train import encode_train   # noqa: WPS433  (kept out of the inference import path)
                 return encode_train(self, x)
-            packed = self._cache.get(self, self.in_channels, 32, prefix="encoder.")
-            _, g, f1, f2, f3 = _rt.forward_eval(x, packed, 32, want_features=True, want_embedding=False)
+            packed = self._cache.get(self, self.in_channels, 32, prefix="encoder.", precision=self.precision)
+            _, g, f1, f2, f3 = _rt.forward_eval(x, packed, 32, want_features=True, want_embedding=False,
+                                                precision=self.precision)
             return f1, f2, f3, g
         # CPU: stock PyTorch, same op sequence as reference point2net.py:36-48
         x = x.transpose(1, 2)
@@ -95,6 +98,9 @@ class Point2Net(nn.Module):
             nn.Conv1d(256 + 256, 256, 1), nn.BatchNorm1d(256), nn.ReLU(),
             nn.Conv1d(256, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
             nn.Conv1d(128, embedding_dim, 1))
+        # Not in the reference: "fp32" (default, exact-fp32 MFMA, 1e-5 parity) or "bf16" (bf16 MFMA with
+        # fp32 accumulation, 2e-2 parity, GPU eval only).  Plain attribute: not part of the state_dict.
+        self.precision = "fp32"
         self._cache = _PackedCache()
 
     # ---- GPU paths -----------------------------------------------------
@@ -102,8 +108,8 @@ class Point2Net(nn.Module):
         return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def _gpu_eval(self, x, want_global=False, want_features=False):
-        packed = self._cache.get(self, self.feature_dim, self.embedding_dim)
-        return _rt.forward_eval(x, packed, self.embedding_dim, want_global, want_features)
+        packed = self._cache.get(self, self.feature_dim, self.embedding_dim, precision=self.precision)
+        return _rt.forward_eval(x, packed, self.embedding_dim, want_global, want_features, precision=self.precision)
 
     def forward(self, x):
         if x.dim() != 3 or x.size(2) != self.feature_dim:

@@ -39,10 +39,17 @@ def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def pack_eval_params(raw: torch.Tensor, feature_dim: int, embedding_dim: int) -> torch.Tensor:
+PRECISIONS = ("fp32", "bf16")
+
+
+def pack_eval_params(raw: torch.Tensor, feature_dim: int, embedding_dim: int, precision: str = "fp32") -> torch.Tensor:
     """raw flat float32 params on the GPU -> packed eval image (see include/p2n.h)."""
     L = _lib.lib()
-    n = L.p2n_packed_param_count(feature_dim, embedding_dim)
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+    count = L.p2n_packed_param_count if precision == "fp32" else L.p2n_packed_param_count_bf16
+    pack = L.p2n_pack_eval_params if precision == "fp32" else L.p2n_pack_eval_params_bf16
+    n = count(feature_dim, embedding_dim)
     if n < 0:
         raise ValueError(f"unsupported feature_dim={feature_dim} / embedding_dim={embedding_dim} "
                          "(HIP path supports 1..8 / 1..256)")
@@ -51,15 +58,17 @@ def pack_eval_params(raw: torch.Tensor, feature_dim: int, embedding_dim: int) ->
     raw = require_cuda_f32(raw, "raw")
     packed = torch.empty(n, dtype=torch.float32, device=raw.device)
     with torch.cuda.device(raw.device):
-        _lib.check(L.p2n_pack_eval_params(raw.data_ptr(), feature_dim, embedding_dim, packed.data_ptr(),
-                                          stream_handle(raw.device)), "p2n_pack_eval_params")
+        _lib.check(pack(raw.data_ptr(), feature_dim, embedding_dim, packed.data_ptr(), stream_handle(raw.device)),
+                   "p2n_pack_eval_params")
     return packed
 
 
 def forward_eval(x: torch.Tensor, packed: torch.Tensor, embedding_dim: int, want_global: bool = False,
-                 want_features: bool = False, want_embedding: bool = True):
-    """x (B,N,F) -> emb (B,N,E) [, global_f (B,256)] [, f1, f2, f3]."""
+                 want_features: bool = False, want_embedding: bool = True, precision: str = "fp32"):
+    """x (B,N,F) -> emb (B,N,E) [, global_f (B,256)] [, f1, f2, f3].  `packed` must have been built
+    for the same precision."""
     L = _lib.lib()
+    fwd = L.p2n_forward_eval if precision == "fp32" else L.p2n_forward_eval_bf16
     x = require_cuda_f32(x, "x")
     if x.dim() != 3:
         raise ValueError(f"x must be (B,N,C), got {tuple(x.shape)}")
@@ -75,7 +84,6 @@ def forward_eval(x: torch.Tensor, packed: torch.Tensor, embedding_dim: int, want
         nbytes = L.p2n_forward_eval_workspace_bytes(B, N, F, E)
         ws = workspace(nbytes, dev)
         with torch.cuda.device(dev):
-            _lib.check(L.p2n_forward_eval(x.data_ptr(), B, N, F, E, packed.data_ptr(), ptr(emb), ptr(g),
-                                          ptr(f1), ptr(f2), ptr(f3), ws.data_ptr(), ws.numel(),
-                                          stream_handle(dev)), "p2n_forward_eval")
+            _lib.check(fwd(x.data_ptr(), B, N, F, E, packed.data_ptr(), ptr(emb), ptr(g), ptr(f1), ptr(f2), ptr(f3),
+                           ws.data_ptr(), ws.numel(), stream_handle(dev)), "p2n_forward_eval")
     return emb, g, f1, f2, f3
