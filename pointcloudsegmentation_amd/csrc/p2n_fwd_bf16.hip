@@ -17,8 +17,9 @@
 //     (512 B per point written + read instead of 1,024): the head loads them straight into MFMAs;
 //   * the global feature, the folded per-cloud shift of layer 6 (W6[:,256:].g) and all
 //     scale/shift epilogues stay fp32.
-// Weight stream: 1-KiB fragments (64 lanes x 8 bf16) in consumption order, 32-fragment chunks
-// double-buffered in LDS by LDS-DMA, as in the fp32 path.
+// Weight stream: 1-KiB fragments (64 lanes x 8 bf16) in consumption order, 32-fragment chunks in a
+// four-deep LDS ring filled by LDS-DMA (see enter_chunk_b); one workgroup = 8 waves = 256 points.
+#include <stdlib.h>
 #include "p2n_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -49,9 +50,9 @@ static inline P2nLayoutB p2n_make_layout_b(int F, int E) {
     }
     long o = 0;
     L.enc_stream = o; L.enc_frags = 276;
-    o += ((L.enc_frags + P2N_CHUNK - 1) / P2N_CHUNK + 1) * P2N_CHUNK * P2N_FRAG_FLOATS;
+    o += ((L.enc_frags + P2N_CHUNK - 1) / P2N_CHUNK + 3) * P2N_CHUNK * P2N_FRAG_FLOATS;   // + the ring's look-ahead
     L.head_stream = o; L.head_frags = 192 + 8L * L.ct8;
-    o += ((L.head_frags + P2N_CHUNK - 1) / P2N_CHUNK + 1) * P2N_CHUNK * P2N_FRAG_FLOATS;
+    o += ((L.head_frags + P2N_CHUNK - 1) / P2N_CHUNK + 3) * P2N_CHUNK * P2N_FRAG_FLOATS;
     for (int l = 0; l < P2N_NLAYER; ++l) { L.scale[l] = o; o += L.cpad[l]; L.shift[l] = o; o += L.cpad[l]; }
     L.w6g = o; o += 256L * 256;
     L.total = o;
@@ -135,25 +136,43 @@ __global__ void p2n_pack_bf16_kernel(const float *__restrict__ raw, float *__res
 typedef __attribute__((address_space(3))) void lds_void_b;
 typedef const __attribute__((address_space(1))) void gbl_void_b;
 
+// A bf16 chunk is consumed in ~1 us, less than an LDS-DMA takes to land, so the ring is four chunks
+// deep (128 KiB of LDS, one 8-wave workgroup per CU): entering chunk c the workgroup queues chunk
+// c+3 and waits only for chunk c with a COUNTED vmcnt that leaves the two younger chunks in flight.
+#define NWB 8                      // waves per workgroup (256 points)
+#define RING 4
+#define DMA_PER_WAVE (P2N_CHUNK / NWB)
+
 __device__ __forceinline__ void stage_chunk_b(const float *__restrict__ stream, float *wbuf, int c, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < P2N_CHUNK / P2N_WAVES_PER_WG; ++i) {
-        const int f = wave * (P2N_CHUNK / P2N_WAVES_PER_WG) + i;
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int f = wave * DMA_PER_WAVE + i;
         __builtin_amdgcn_global_load_lds((gbl_void_b *)(stream + ((long)c * P2N_CHUNK + f) * P2N_FRAG_FLOATS + lane * 4),
-                                         (lds_void_b *)(wbuf + (c & 1) * BCHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16, 0, 0);
+                                         (lds_void_b *)(wbuf + (c % RING) * BCHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16, 0, 0);
     }
 }
 
-// entering fragment f: at a chunk boundary wait for it (vmcnt(0) + barrier) and start the next chunk's DMA
+// s_waitcnt vmcnt(n) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]);
+// lgkmcnt(0): this wave's own LDS writes (tables) and reads are done before it signals the barrier
+#define WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (0 << 8) | (((n) >> 4) << 14))
+
+// Entering chunk c (every wave, uniformly): this wave's share of chunk c has landed once at most the
+// 2*DMA_PER_WAVE younger DMA instructions (chunks c+1, c+2) are outstanding -- vmcnt retires in issue
+// order, and anything else the wave queued since only makes the wait stricter; the barrier then makes
+// every wave's share visible and proves that all waves have left chunk c-1, whose buffer chunk c+3 takes.
+__device__ __forceinline__ void enter_chunk_b(int c, const float *__restrict__ stream, float *wbuf, int wave, int lane) {
+    WAIT_VMCNT(2 * DMA_PER_WAVE);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage_chunk_b(stream, wbuf, c + RING - 1, wave, lane);
+}
+
 __device__ __forceinline__ void gate_b(int f, const float *__restrict__ stream, float *wbuf, int wave, int lane) {
-    if (f % P2N_CHUNK == 0) {
-        __syncthreads();
-        stage_chunk_b(stream, wbuf, f / P2N_CHUNK + 1, wave, lane);
-    }
+    if (f % P2N_CHUNK == 0) enter_chunk_b(f / P2N_CHUNK, stream, wbuf, wave, lane);
 }
 
 __device__ __forceinline__ bf16x8 frag_b(const float *wbuf, int f, int lane) {
-    return *reinterpret_cast<const bf16x8 *>(wbuf + ((f / P2N_CHUNK) & 1) * BCHUNK_FLOATS + (f % P2N_CHUNK) * P2N_FRAG_FLOATS +
+    return *reinterpret_cast<const bf16x8 *>(wbuf + ((f / P2N_CHUNK) % RING) * BCHUNK_FLOATS + (f % P2N_CHUNK) * P2N_FRAG_FLOATS +
                                              lane * 4);
 }
 
@@ -198,11 +217,22 @@ __device__ __forceinline__ f32x16 zero16() {
 // one output tile of a plain bf16 layer: KS k-steps, fragments F0 .. F0+KS-1
 template <int KS, int F0>
 __device__ __forceinline__ f32x16 tile_plain(const float *stream, float *wbuf, int wave, int lane, const bf16x8 (&in)[KS]) {
+    // all KS fragments of the tile are fetched before its MFMAs start (a chunk boundary may fall inside:
+    // the fetch stops there, crosses the gate, and goes on)
     f32x16 acc = zero16();
+    bf16x8 w[KS];
+    constexpr int SPLIT = ((F0 / P2N_CHUNK) != ((F0 + KS - 1) / P2N_CHUNK)) ? ((F0 / P2N_CHUNK + 1) * P2N_CHUNK - F0) : KS;
+    if (F0 % P2N_CHUNK == 0) gate_b(F0, stream, wbuf, wave, lane);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        gate_b(F0 + ks, stream, wbuf, wave, lane);
-        acc = MFMAB(frag_b(wbuf, F0 + ks, lane), in[ks], acc);
+    for (int ks = 0; ks < SPLIT; ++ks) w[ks] = frag_b(wbuf, F0 + ks, lane);
+#pragma unroll
+    for (int ks = 0; ks < SPLIT; ++ks) acc = MFMAB(w[ks], in[ks], acc);
+    if (SPLIT < KS) {
+        gate_b(F0 + SPLIT, stream, wbuf, wave, lane);
+#pragma unroll
+        for (int ks = SPLIT; ks < KS; ++ks) w[ks] = frag_b(wbuf, F0 + ks, lane);
+#pragma unroll
+        for (int ks = SPLIT; ks < KS; ++ks) acc = MFMAB(w[ks], in[ks], acc);
     }
     return acc;
 }
@@ -238,6 +268,35 @@ __device__ __forceinline__ unsigned row_max_u32_b(unsigned v) {
     return v;
 }
 
+// Channel maxima of one tile over each 16-lane row of points, as a halving transpose-reduce: at every
+// step lanes pair up (xor 1, xor 2, rotate 4, rotate 8 inside the DPP row), each lane keeps one register
+// of a pair and takes the partner's copy of it, so 16 registers shrink to 8, 4, 2, 1 with 15 DPP moves
+// instead of 64.  Lane i of a row ends up with the row maximum of register i, i.e. of channel
+// 32ct + 8(i>>2) + 4h + (i&3).  Post-ReLU values are >= 0: their bit patterns order as unsigned integers and
+// 0 is the neutral element for masked points.  No LDS traffic here: an LDS atomic issued while weight DMAs
+// are in flight makes the compiler drain them first (s_waitcnt vmcnt(0)).
+template <int N, int CTRL>
+__device__ __forceinline__ void halve_max(unsigned (&m)[16], bool upper) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const unsigned keep = upper ? m[2 * q + 1] : m[2 * q];
+        const unsigned give = upper ? m[2 * q] : m[2 * q + 1];
+        const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give, CTRL, 0xF, 0xF, true);
+        m[q] = keep > t ? keep : t;
+    }
+}
+
+__device__ __forceinline__ unsigned tile_rowmax(const f32x16 v, bool valid, int lane) {
+    unsigned m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = valid ? __float_as_uint(v[i]) : 0u;
+    halve_max<8, 0xB1>(m, lane & 1);    // quad_perm [1,0,3,2]
+    halve_max<4, 0x4E>(m, lane & 2);    // quad_perm [2,3,0,1]
+    halve_max<2, 0x124>(m, lane & 4);   // row_ror:4
+    halve_max<1, 0x128>(m, lane & 8);   // row_ror:8
+    return m[0];
+}
+
 template <int C>
 __device__ __forceinline__ void store_feat_b(float *__restrict__ f, const f32x16 v, int b, int ct, int h, long n, int N) {
     if (n >= N) return;
@@ -258,26 +317,31 @@ struct EncArgsB {
     long stream, tab;
     int tab_n;
     int scale[6], shift[6];
+    int dbg;
 };
 
-#define ENCB_LDS_FLOATS (2 * BCHUNK_FLOATS + 256 + P2N_TAB_MAX)
+#define ENCB_LDS_FLOATS (RING * BCHUNK_FLOATS)
 
 template <bool FEATS>
-__global__ __launch_bounds__(256, 2) void p2n_encoder_bf16_kernel(EncArgsB A) {
+__global__ __launch_bounds__(NWB * 64, 2) void p2n_encoder_bf16_kernel(EncArgsB A) {
+    // the weight ring is the only dynamic LDS: channel maxima and tables are separate static arrays, so the
+    // compiler can tell that LDS atomics / table reads never alias an in-flight LDS-DMA (otherwise every
+    // ds_max is preceded by s_waitcnt vmcnt(0), which drains the whole look-ahead)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ unsigned smax[256];
+    __shared__ __attribute__((aligned(16))) float tab[P2N_TAB_MAX];
     float *wbuf = lds;
-    unsigned *smax = reinterpret_cast<unsigned *>(lds + 2 * BCHUNK_FLOATS);
-    float *tab = lds + 2 * BCHUNK_FLOATS + 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / A.tiles, tile = blockIdx.x % A.tiles;
-    const long n = ((long)tile * P2N_WAVES_PER_WG + wave) * P2N_PTS_PER_WAVE + p;
+    const long n = ((long)tile * NWB + wave) * P2N_PTS_PER_WAVE + p;
     const float *stream = A.packed + A.stream;
-    stage_chunk_b(stream, wbuf, 0, wave, lane);
-    for (int i = threadIdx.x; i < A.tab_n; i += 256) tab[i] = A.packed[A.tab + i];
-    smax[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < A.tab_n; i += NWB * 64) tab[i] = A.packed[A.tab + i];   // queued before the DMA
+    if (threadIdx.x < 256) smax[threadIdx.x] = 0u;
+#pragma unroll
+    for (int c = 0; c < RING - 1; ++c) stage_chunk_b(stream, wbuf, c, wave, lane);
     const bool valid = n < A.N;
-    const long grp = (long)blockIdx.x * P2N_WAVES_PER_WG + wave;
+    const long grp = (long)blockIdx.x * NWB + wave;
 
     // layer 0 operand (natural k order): lane half 0 holds features 0..7, half 1 the zero padding of K = 16
     bf16x8 x_hi[1], x_lo[1];
@@ -338,22 +402,25 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_bf16_kernel(EncArgsB A) {
 #undef P2N_L4
     // ---- layer 5: 256 -> 256                 fragments 148..275; results leave through the spill and the max
     char *sp = reinterpret_cast<char *>(A.spill) + grp * (16L * 1024) + lane * 16;
+    unsigned wm[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // this lane's row maxima, one per output tile
 #define P2N_L5(ct) { const f32x16 acc = tile_plain<16, 148 + 16 * (ct)>(stream, wbuf, wave, lane, a4);            \
                      const f32x16 v = epilogue_b<true>(acc, tab + A.scale[5], tab + A.shift[5], (ct), h);          \
                      if (FEATS) if (A.f3) store_feat_b<256>(A.f3, v, b, (ct), h, n, A.N);                          \
                      bf16x8 s0, s1;                                                                                \
                      pack_tile(v, s0, s1);                                                                         \
-                     *reinterpret_cast<bf16x8 *>(sp + (2 * (ct)) * 1024) = s0;                                     \
-                     *reinterpret_cast<bf16x8 *>(sp + (2 * (ct) + 1) * 1024) = s1;                                 \
-                     _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                 \
-                     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-                         const unsigned m = row_max_u32_b(valid ? __float_as_uint(v[4 * g + j]) : 0u);             \
-                         if ((lane & 15) == 0) atomicMax(&smax[32 * (ct) + 8 * g + 4 * h + j], m);                 \
-                     } }
+                     if (!(A.dbg & 2)) { *reinterpret_cast<bf16x8 *>(sp + (2 * (ct)) * 1024) = s0;                 \
+                     *reinterpret_cast<bf16x8 *>(sp + (2 * (ct) + 1) * 1024) = s1; }                               \
+                     if (!(A.dbg & 1)) wm[(ct)] = tile_rowmax(v, valid, lane); }
     P2N_L5(0) P2N_L5(1) P2N_L5(2) P2N_L5(3) P2N_L5(4) P2N_L5(5) P2N_L5(6) P2N_L5(7)
 #undef P2N_L5
-    __syncthreads();   // also drains the spare chunk's DMA
-    A.partial[(long)blockIdx.x * 256 + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
+    __syncthreads();   // drains the look-ahead DMAs (before the workgroup's LDS is released and before the atomics)
+    {
+        const int i = lane & 15;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) atomicMax(&smax[32 * ct + 8 * (i >> 2) + 4 * h + (i & 3)], wm[ct]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) A.partial[(long)blockIdx.x * 256 + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ mid (fp32; same arithmetic as p2n_fwd.hip)
@@ -393,26 +460,27 @@ struct HeadArgsB {
     int scale6, scale7, shift7, scale8, shift8;
 };
 
-__global__ __launch_bounds__(256, 2) void p2n_head_bf16_kernel(HeadArgsB A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__global__ __launch_bounds__(NWB * 64, 2) void p2n_head_bf16_kernel(HeadArgsB A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // the weight ring only (see the encoder)
+    __shared__ __attribute__((aligned(16))) float tab[2 * (256 + 128 + 256)];
+    __shared__ __attribute__((aligned(16))) float sh6[256];
     float *wbuf = smem;
-    float *tab = smem + 2 * BCHUNK_FLOATS;
-    float *sh6 = tab + A.tab_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / A.tiles, tile = blockIdx.x % A.tiles;
-    const long n0 = ((long)tile * P2N_WAVES_PER_WG + wave) * P2N_PTS_PER_WAVE;
-    const long grp = (long)blockIdx.x * P2N_WAVES_PER_WG + wave;
+    const long n0 = ((long)tile * NWB + wave) * P2N_PTS_PER_WAVE;
+    const long grp = (long)blockIdx.x * NWB + wave;
     const float *stream = A.packed + A.stream;
-    stage_chunk_b(stream, wbuf, 0, wave, lane);
-    for (int i = threadIdx.x; i < A.tab_n; i += 256) tab[i] = A.packed[A.tab + i];
-    sh6[threadIdx.x] = A.shift6c[(long)b * 256 + threadIdx.x];
+    for (int i = threadIdx.x; i < A.tab_n; i += NWB * 64) tab[i] = A.packed[A.tab + i];
+    if (threadIdx.x < 256) sh6[threadIdx.x] = A.shift6c[(long)b * 256 + threadIdx.x];
 
     // f3 of this wave's 32 points: 16 operand fragments, exactly as the encoder packed them
     const char *sp = reinterpret_cast<const char *>(A.spill) + grp * (16L * 1024) + lane * 16;
     bf16x8 f3[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) f3[ks] = *reinterpret_cast<const bf16x8 *>(sp + ks * 1024);
+#pragma unroll
+    for (int c = 0; c < RING - 1; ++c) stage_chunk_b(stream, wbuf, c, wave, lane);   // behind the f3 loads in the queue
 
     // ---- layer 6: 256 (+ folded global half) -> 256     fragments 0..127
     bf16x8 a6[16];
@@ -438,9 +506,8 @@ __global__ __launch_bounds__(256, 2) void p2n_head_bf16_kernel(HeadArgsB A) {
 #pragma unroll 1
     for (int c8 = 0; c8 < nch8; ++c8) {
         const int c = 6 + c8;
-        __syncthreads();
-        stage_chunk_b(stream, wbuf, c + 1, wave, lane);
-        const float *wb = wbuf + (c & 1) * BCHUNK_FLOATS + lane * 4;
+        enter_chunk_b(c, stream, wbuf, wave, lane);
+        const float *wb = wbuf + (c % RING) * BCHUNK_FLOATS + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ct8 = 4 * c8 + q;
@@ -469,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void p2n_head_bf16_kernel(HeadArgsB A) {
             }
         }
     }
-    __syncthreads();   // drain the spare chunk's DMA before the workgroup's LDS is released
+    __syncthreads();   // drain the look-ahead DMAs before the workgroup's LDS is released
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -489,7 +556,7 @@ extern "C" int p2n_pack_eval_params_bf16(const float *raw, int F, int E, float *
     return P2N_OK;
 }
 
-static inline int tiles_per_cloud_b(int N) { return (N + P2N_PTS_PER_WG - 1) / P2N_PTS_PER_WG; }
+static inline int tiles_per_cloud_b(int N) { return (N + NWB * P2N_PTS_PER_WAVE - 1) / (NWB * P2N_PTS_PER_WAVE); }
 
 template <typename K>
 static int allow_big_lds_b(K kernel, size_t bytes) {
@@ -522,13 +589,14 @@ extern "C" int p2n_forward_eval_bf16(const float *x, int B, int N, int F, int E,
     const int tiles = tiles_per_cloud_b(N);
     const size_t ntiles = (size_t)B * tiles;
     float *spill = (float *)workspace;
-    float *partial = spill + ntiles * P2N_WAVES_PER_WG * 256 * P2N_PTS_PER_WAVE;   // same carve as the fp32 path
+    float *partial = spill + ntiles * NWB * 4096;   // 16 KiB of bf16 fragments per wave; all of it inside the fp32 bound
     float *shift6c = partial + ntiles * 256;
 
     EncArgsB ea;
     ea.x = x; ea.packed = packed; ea.spill = spill; ea.partial = partial;
     ea.f1 = f1; ea.f2 = f2; ea.f3 = f3;
     ea.N = N; ea.F = F; ea.tiles = tiles; ea.stream = L.enc_stream;
+    { const char *d = getenv("P2N_DBG"); ea.dbg = d ? atoi(d) : 0; }
     ea.tab = L.scale[0]; ea.tab_n = (int)(L.scale[6] - L.scale[0]);
     for (int l = 0; l < 6; ++l) { ea.scale[l] = (int)(L.scale[l] - L.scale[0]); ea.shift[l] = (int)(L.shift[l] - L.scale[0]); }
     const size_t enc_lds = sizeof(float) * ENCB_LDS_FLOATS;
@@ -536,11 +604,11 @@ extern "C" int p2n_forward_eval_bf16(const float *x, int B, int N, int F, int E,
     if (f1 || f2 || f3) {
         int rc = allow_big_lds_b(p2n_encoder_bf16_kernel<true>, enc_lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(p2n_encoder_bf16_kernel<true>, dim3((unsigned)ntiles), dim3(256), enc_lds, stream, ea);
+        hipLaunchKernelGGL(p2n_encoder_bf16_kernel<true>, dim3((unsigned)ntiles), dim3(NWB * 64), enc_lds, stream, ea);
     } else {
         int rc = allow_big_lds_b(p2n_encoder_bf16_kernel<false>, enc_lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(p2n_encoder_bf16_kernel<false>, dim3((unsigned)ntiles), dim3(256), enc_lds, stream, ea);
+        hipLaunchKernelGGL(p2n_encoder_bf16_kernel<false>, dim3((unsigned)ntiles), dim3(NWB * 64), enc_lds, stream, ea);
     }
     p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
@@ -556,13 +624,13 @@ extern "C" int p2n_forward_eval_bf16(const float *x, int B, int N, int F, int E,
     ha.tab = L.scale[6]; ha.tab_n = (int)(L.w6g - L.scale[6]);
     ha.scale6 = 0; ha.scale7 = (int)(L.scale[7] - L.scale[6]); ha.shift7 = (int)(L.shift[7] - L.scale[6]);
     ha.scale8 = (int)(L.scale[8] - L.scale[6]); ha.shift8 = (int)(L.shift[8] - L.scale[6]);
-    const size_t lds = sizeof(float) * (2 * (size_t)BCHUNK_FLOATS + ha.tab_n + 256);
+    const size_t lds = sizeof(float) * RING * (size_t)BCHUNK_FLOATS;
     {
         int rc = allow_big_lds_b(p2n_head_bf16_kernel, lds);
         if (rc) return rc;
     }
     ps = p2n_prof_begin(P2N_K_HEAD, stream);
-    hipLaunchKernelGGL(p2n_head_bf16_kernel, dim3((unsigned)ntiles), dim3(256), lds, stream, ha);
+    hipLaunchKernelGGL(p2n_head_bf16_kernel, dim3((unsigned)ntiles), dim3(NWB * 64), lds, stream, ha);
     p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
