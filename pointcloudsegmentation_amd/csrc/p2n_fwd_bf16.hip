@@ -19,7 +19,6 @@
 //     scale/shift epilogues stay fp32.
 // Weight stream: 1-KiB fragments (64 lanes x 8 bf16) in consumption order, 32-fragment chunks in a
 // four-deep LDS ring filled by LDS-DMA (see enter_chunk_b); one workgroup = 8 waves = 256 points.
-#include <stdlib.h>
 #include "p2n_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -317,7 +316,6 @@ struct EncArgsB {
     long stream, tab;
     int tab_n;
     int scale[6], shift[6];
-    int dbg;
 };
 
 #define ENCB_LDS_FLOATS (RING * BCHUNK_FLOATS)
@@ -408,9 +406,9 @@ __global__ __launch_bounds__(NWB * 64, 2) void p2n_encoder_bf16_kernel(EncArgsB 
                      if (FEATS) if (A.f3) store_feat_b<256>(A.f3, v, b, (ct), h, n, A.N);                          \
                      bf16x8 s0, s1;                                                                                \
                      pack_tile(v, s0, s1);                                                                         \
-                     if (!(A.dbg & 2)) { *reinterpret_cast<bf16x8 *>(sp + (2 * (ct)) * 1024) = s0;                 \
-                     *reinterpret_cast<bf16x8 *>(sp + (2 * (ct) + 1) * 1024) = s1; }                               \
-                     if (!(A.dbg & 1)) wm[(ct)] = tile_rowmax(v, valid, lane); }
+                     *reinterpret_cast<bf16x8 *>(sp + (2 * (ct)) * 1024) = s0;                                     \
+                     *reinterpret_cast<bf16x8 *>(sp + (2 * (ct) + 1) * 1024) = s1;                                 \
+                     wm[(ct)] = tile_rowmax(v, valid, lane); }
     P2N_L5(0) P2N_L5(1) P2N_L5(2) P2N_L5(3) P2N_L5(4) P2N_L5(5) P2N_L5(6) P2N_L5(7)
 #undef P2N_L5
     __syncthreads();   // drains the look-ahead DMAs (before the workgroup's LDS is released and before the atomics)
@@ -596,7 +594,6 @@ extern "C" int p2n_forward_eval_bf16(const float *x, int B, int N, int F, int E,
     ea.x = x; ea.packed = packed; ea.spill = spill; ea.partial = partial;
     ea.f1 = f1; ea.f2 = f2; ea.f3 = f3;
     ea.N = N; ea.F = F; ea.tiles = tiles; ea.stream = L.enc_stream;
-    { const char *d = getenv("P2N_DBG"); ea.dbg = d ? atoi(d) : 0; }
     ea.tab = L.scale[0]; ea.tab_n = (int)(L.scale[6] - L.scale[0]);
     for (int l = 0; l < 6; ++l) { ea.scale[l] = (int)(L.scale[l] - L.scale[0]); ea.shift[l] = (int)(L.shift[l] - L.scale[0]); }
     const size_t enc_lds = sizeof(float) * ENCB_LDS_FLOATS;
