@@ -31,19 +31,26 @@ class _PackedCache:
     def __init__(self):
         self.key = None
         self.packed = None
+        self._perm = None
+        self._count = -1
 
     def get(self, module: nn.Module, feature_dim: int, embedding_dim: int, prefix: str = "",
             precision: str = "fp32") -> torch.Tensor:
         """prefix="" : module is a Point2Net.  prefix="encoder.": module is a bare
         PointNet2Encoder; the head slots of the image are zero-filled (never read:
         the head kernel is skipped when no embedding is requested)."""
-        sd = dict(module.named_parameters())
-        sd.update(dict(module.named_buffers()))
-        order = _params.flat_order()
-        if prefix:
-            order = [k[len(prefix):] for k in order if k.startswith(prefix)]
-        tensors = [sd[k] for k in order]
-        key = (precision,) + tuple((t.data_ptr(), t._version) for t in tensors)
+        # hot path: this runs on every forward.  parameters()/buffers() walk the module tree in a fixed
+        # order; the permutation into flat (layer-major) order is worked out once per module structure.
+        ps = list(module.parameters()) + list(module.buffers())
+        if self._perm is None or self._count != len(ps):
+            names = [n for n, _ in module.named_parameters()] + [n for n, _ in module.named_buffers()]
+            order = _params.flat_order()
+            if prefix:
+                order = [k[len(prefix):] for k in order if k.startswith(prefix)]
+            self._perm = [names.index(k) for k in order]
+            self._count = len(ps)
+        tensors = [ps[i] for i in self._perm]
+        key = (precision,) + tuple([(t.data_ptr(), t._version) for t in tensors])
         if key != self.key:
             parts = [t.detach().reshape(-1).to(torch.float32) for t in tensors]
             have = sum(p.numel() for p in parts)
