@@ -158,6 +158,9 @@ struct ClArgs {
     int *nbr_cnt, *nbr;     // pass 2: core neighbours of non-core rows, `cap` slots per row
     int cap;
     int nsplit;
+    const int *act_cnt;     // per 128-point row block: number of active 128-point blocks
+    const int *act_list;    // [row block][nb128]: their indices, ascending
+    int nb128;
     unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
 };
 
@@ -174,6 +177,7 @@ struct ClArgs {
 #define CL_BLK_FLOATS (8192 + 128)   // 32 fragments + nh[128] per LDS buffer
 #define CL_PAR_BASE (2 * CL_BLK_FLOATS)   // then three rotating parent[128] slots (pass 2)
 #define CL_LDS_FLOATS (CL_PAR_BASE + 3 * 128)
+#define CL_SLIST_MAX 2048   // active-list entries one workgroup may hold in LDS (after the ring)
 
 #define CL_NW 4   // waves per workgroup: 128 wave-owned points share one streamed block (6 or 8 waves spill: measured slower)
 #define CL_ROWBLK (CL_NW * 32)
@@ -192,10 +196,17 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
     const long i0 = ((long)blockIdx.x * CL_NW + wave) * 32;
     const long my = i0 + c;               // the point this lane owns
 
-    const long nblk = A.Npad / JB;
-    const long jb0 = nblk * blockIdx.y / A.nsplit, jb1 = nblk * (blockIdx.y + 1) / A.nsplit;
-    const long len = jb1 - jb0;
+    // The streamed blocks of this row block come from its active list: 128-point blocks whose bounding
+    // sphere can reach ours within eps (cl_active_kernel); everything else is skipped without a load.
+    constexpr int SUB = 128 / JB;         // streamed blocks per 128-point block
+    const int total = A.act_cnt[blockIdx.x];
+    const int e0 = (int)((long)total * blockIdx.y / A.nsplit), e1 = (int)((long)total * (blockIdx.y + 1) / A.nsplit);
+    const long len = (long)(e1 - e0) * SUB;
     if (len <= 0) return;
+    int *slist = reinterpret_cast<int *>(lds + CL_LDS_FLOATS);   // this workgroup's slice of the list
+    for (int i = threadIdx.x; i < e1 - e0; i += CL_NW * 64) slist[i] = A.act_list[(long)blockIdx.x * A.nb128 + e0 + i];
+    __syncthreads();
+    auto jbof = [&](long pos) -> long { return (long)slist[pos / SUB] * SUB + pos % SUB; };
     // Pass 1: every workgroup walks the blocks in the same order (a block is fetched from HBM once per
     // XCD, then served from its L2).  Pass 2: staggered starts spread the union-find merges instead of
     // piling every workgroup onto one block's roots at the same time.
@@ -223,8 +234,11 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
     // the block's last unit), so three slots keep writer and readers apart.
     const bool pfetch = MODE == 1 && wave >= 2 && (wave - 2) * 64 < JB;
     const int pslot = CL_PAR_BASE + (wave - 2) * 64 + lane;
-    stage(jb0 + cur, 0);
-    if (pfetch) lds[pslot] = __int_as_float(CL_LD(A.parent + (jb0 + cur) * JB + (wave - 2) * 64 + lane));
+    // block numbers are looked up one step ahead of their use: the LDS read is off the critical path
+    long jb_now = jbof(cur);
+    long jb_nxt = jbof(cur + 1 == len ? 0 : cur + 1);
+    stage(jb_now, 0);
+    if (pfetch) lds[pslot] = __int_as_float(CL_LD(A.parent + jb_now * JB + (wave - 2) * 64 + lane));
     int pnext = 0;
 
     f32x4 a[G];
@@ -322,13 +336,17 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
         constexpr int u = decltype(uconst)::value;   // w % UPS, known at compile time (w advances in pairs)
         if (w < W) {
             if (u == 0) {
-                jb_cur = jb0 + cur;
+                jb_cur = jb_now;
                 const long nxt = (cur + 1 == len) ? 0 : cur + 1;
+                const long nn = (nxt + 1 == len) ? 0 : nxt + 1;
+                const long jb_after = jbof(nn);
                 __syncthreads();   // block jb_cur has landed (vmcnt(0) + barrier); the other buffer is free
                 if (MODE == 1) pi = CL_LD(A.parent + my);   // queued before the DMA: vmcnt completes in order
-                if (pfetch && t + 1 < len) pnext = CL_LD(A.parent + (jb0 + nxt) * JB + (wave - 2) * 64 + lane);
-                if (t + 1 < len) stage(jb0 + nxt, (int)((t + 1) & 1));
+                if (pfetch && t + 1 < len) pnext = CL_LD(A.parent + jb_nxt * JB + (wave - 2) * 64 + lane);
+                if (t + 1 < len) stage(jb_nxt, (int)((t + 1) & 1));
                 cur = nxt;
+                jb_now = jb_nxt;
+                jb_nxt = jb_after;
                 blk_active = MODE == 0 || A.colblk_has_core[(jb_cur * JB) >> 7] != 0;
             }
             active = blk_active;
@@ -380,6 +398,88 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
         cntd += __shfl_xor(cntd, 32);   // the two lane halves saw different rows of the same point
         if (h == 0 && cntd) atomicAdd(A.cnt + my, cntd);
     }
+}
+
+// ------------------------------------------------------------------ block pruning
+// Bounding sphere of every 128-point block (centre = mean, radius = max distance to it, real rows only).
+// Embeddings of one instance sit close together and scans are index-coherent, so most block pairs of a
+// scene are farther apart than eps and never need their 128 x 128 distance tile.
+#define CL_SPH_MARGIN 1e-4f   // fp32 slack of centre / radius / centre-distance arithmetic (vectors are unit length)
+__global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
+                                                        float *__restrict__ centre, float *__restrict__ radius) {
+    extern __shared__ float sph[];   // [8G] centre, then reduction scratch
+    float *cen = sph, *red = sph + 8 * G;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const long i = (long)b * 128 + t;
+    const bool real = nh[i] > -__builtin_inff();
+    const float *px = Xp + ((i >> 5) * G * 64 + (i & 31)) * 4;
+    // count of real rows
+    red[t] = real ? 1.f : 0.f;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const float cntf = red[0];
+    __syncthreads();
+    if (cntf == 0.f) { if (t == 0) radius[b] = -1.f; if (t < 8 * G) centre[(long)b * 8 * G + t] = 0.f; return; }
+    for (int k = 0; k < 8 * G; ++k) {   // column means (D <= 256: at most 256 short reductions)
+        const float v = real ? px[(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (k & 3)] : 0.f;
+        red[t] = v;
+        __syncthreads();
+        for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+        if (t == 0) cen[k] = red[0] / cntf;
+        __syncthreads();
+    }
+    float d2 = 0.f;
+    if (real)
+        for (int k = 0; k < 8 * G; ++k) {
+            const float d = px[(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (k & 3)] - cen[k];
+            d2 = fmaf(d, d, d2);
+        }
+    red[t] = d2;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
+    if (t == 0) radius[b] = sqrtf(red[0]) + CL_SPH_MARGIN;
+    if (t < 8 * G) centre[(long)b * 8 * G + t] = cen[t];
+}
+
+// grid = row blocks.  list[ib][0..cnt) = column blocks jb (ascending) with |c_ib - c_jb| <= r_ib + r_jb + eps.
+__global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict__ centre, const float *__restrict__ radius,
+                                                        int nb, int Dp, float eps, int *__restrict__ act_cnt,
+                                                        int *__restrict__ act_list) {
+    extern __shared__ float ci[];   // [Dp] own centre, then [256] ints scan scratch
+    int *scan = reinterpret_cast<int *>(ci + Dp);
+    __shared__ int base;
+    const int ib = blockIdx.x, t = threadIdx.x;
+    for (int k = t; k < Dp; k += 256) ci[k] = centre[(long)ib * Dp + k];
+    if (t == 0) base = 0;
+    __syncthreads();
+    const float ri = radius[ib];
+    for (int j0 = 0; j0 < nb; j0 += 256) {
+        const int jb = j0 + t;
+        int act = 0;
+        if (jb < nb && ri >= 0.f) {
+            const float rj = radius[jb];
+            if (rj >= 0.f) {
+                float d2 = 0.f;
+                const float *cj = centre + (long)jb * Dp;
+                for (int k = 0; k < Dp; ++k) { const float d = ci[k] - cj[k]; d2 = fmaf(d, d, d2); }
+                const float reach = ri + rj + eps + CL_SPH_MARGIN;
+                act = d2 <= reach * reach;
+            }
+        }
+        scan[t] = act;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
+            const int v = t >= o ? scan[t - o] : 0;
+            __syncthreads();
+            scan[t] += v;
+            __syncthreads();
+        }
+        if (act) act_list[(long)ib * nb + base + scan[t] - 1] = jb;
+        __syncthreads();
+        if (t == 255) base += scan[255];
+        __syncthreads();
+    }
+    if (t == 0) act_cnt[ib] = base;
 }
 
 // ------------------------------------------------------------------ glue kernels
@@ -457,6 +557,8 @@ struct ClWs {
     int *cnt, *parent, *nbr_cnt, *rank, *blk_has_core, *nbr;
     unsigned char *core;
     unsigned long long *stats;
+    float *centre, *radius;
+    int *act_cnt, *act_list;
 };
 
 static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
@@ -476,6 +578,13 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
     w.blk_has_core = (int *)take(sizeof(int) * (Npad / 128 + 1));
     w.core = (unsigned char *)take((size_t)Npad);
     w.stats = (unsigned long long *)take(sizeof(unsigned long long) * 8);
+    {
+        const size_t nb = (size_t)Npad / 128;
+        w.centre = (float *)take(sizeof(float) * nb * G * 8);
+        w.radius = (float *)take(sizeof(float) * nb);
+        w.act_cnt = (int *)take(sizeof(int) * nb);
+        w.act_list = (int *)take(sizeof(int) * nb * nb);
+    }
     w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
     return o;
 }
@@ -516,7 +625,7 @@ extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, v
 
 template <int G, int CT>
 static int cl_launch_pairs(int mode, const ClArgs &a, long nrowblk, hipStream_t stream) {
-    const size_t ldsb = CL_LDS_FLOATS * sizeof(float);   // 66 KiB: above the default dynamic-LDS limit
+    const size_t ldsb = (CL_LDS_FLOATS + CL_SLIST_MAX) * sizeof(float);   // 76 KiB: above the default dynamic-LDS limit
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 1>),
@@ -552,6 +661,11 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const unsigned nb256 = (unsigned)((Npad + 255) / 256);
     int ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
     hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm);
+    const int nb128 = (int)(Npad / 128);
+    hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (8 * G + 128), stream, w.Xp, w.nrm, G, w.centre,
+                       w.radius);
+    hipLaunchKernelGGL(cl_active_kernel, dim3(nb128), dim3(256), sizeof(float) * (8 * G + 256), stream, w.centre, w.radius, nb128,
+                       8 * G, (float)eps, w.act_cnt, w.act_list);
     P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.blk_has_core, 0, sizeof(int) * (Npad / 128 + 1), stream));
@@ -568,6 +682,8 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     long ns = (2048 + nrowblk - 1) / nrowblk;            // enough workgroups to fill 256 CUs x 2 several times
     const long ncolblk = Npad / (CT * 32);
     a.nsplit = (int)(ns < 1 ? 1 : (ns > ncolblk ? ncolblk : ns));
+    if ((long)a.nsplit * CL_SLIST_MAX < nb128) a.nsplit = (int)((nb128 + CL_SLIST_MAX - 1) / CL_SLIST_MAX);   // a list slice must fit in LDS
+    a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128;
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
     if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, nrowblk, stream);

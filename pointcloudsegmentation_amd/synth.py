@@ -68,13 +68,16 @@ def make_labels(b: int, n: int, seed: int, num_instances: int = 33) -> np.ndarra
 
 
 def make_embeddings(n: int, d: int, seed: int, n_clusters: int = 33, noise_frac: float = 0.1,
-                    spread=(0.02, 0.12), intrinsic_dim: int = 4) -> np.ndarray:
+                    spread=(0.02, 0.12), intrinsic_dim: int = 4, order: str = "random") -> np.ndarray:
     """Instance-embedding-shaped rows (n, d) fp32: `n_clusters` directions on the unit sphere,
     each with its own spread inside a random `intrinsic_dim`-dimensional subspace (density falls
     off smoothly, so at DBSCAN eps = 0.1 there are dense cores, border points, noise tails and
     clusters that touch), plus `noise_frac` of uniformly random directions; rows carry
     random positive lengths so the caller's L2 normalisation matters.  Cluster sizes are
-    uneven (ScanNet instances: a few large structures, many small objects)."""
+    uneven (ScanNet instances: a few large structures, many small objects).
+    order="random": rows shuffled (worst case for any locality); order="runs": rows of one
+    instance come in runs of 64-2048, noise rows scattered between them -- the index coherence of
+    a scanned mesh, whose vertex order follows the surface."""
     rng = np.random.default_rng(seed)
     n_noise = int(n * noise_frac)
     n_in = n - n_noise
@@ -92,4 +95,23 @@ def make_embeddings(n: int, d: int, seed: int, n_clusters: int = 33, noise_frac:
     allp = np.concatenate([pts, noise], 0)
     allp /= np.linalg.norm(allp, axis=1, keepdims=True)
     allp *= rng.uniform(0.5, 3.0, size=(n, 1))
-    return np.ascontiguousarray(allp[rng.permutation(n)], dtype=np.float32)
+    if order == "random":
+        perm = rng.permutation(n)
+    elif order == "runs":
+        src = [list(rng.permutation(np.flatnonzero(which == c))) for c in range(max(n_clusters, 1))]
+        noise_ids = list(rng.permutation(np.arange(n_in, n)))
+        perm = []
+        live = [c for c in range(len(src)) if src[c]]
+        while live or noise_ids:
+            if live:
+                c = live[int(rng.integers(len(live)))]
+                k = int(rng.integers(64, 2049))
+                perm.extend(src[c][:k]); del src[c][:k]
+                if not src[c]:
+                    live.remove(c)
+            k = int(rng.integers(0, 1 + max(1, int(0.25 * n_noise / max(n_in / 1000, 1)))))
+            perm.extend(noise_ids[:k]); del noise_ids[:k]
+        perm = np.asarray(perm)
+    else:
+        raise ValueError(f"unknown order {order!r}")
+    return np.ascontiguousarray(allp[perm], dtype=np.float32)

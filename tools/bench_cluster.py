@@ -16,9 +16,10 @@ ap.add_argument("--n", type=int, default=166499)
 ap.add_argument("--d", type=int, default=64)
 ap.add_argument("--clusters", type=int, default=33)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--order", default="runs", choices=["runs", "random"], help="row order of the synthetic embeddings")
 ap.add_argument("--cpu-n", type=int, default=30000, help="subsample size for the scikit-learn leg (0 = skip)")
 a = ap.parse_args()
-e_np = make_embeddings(a.n, a.d, 11, n_clusters=a.clusters)
+e_np = make_embeddings(a.n, a.d, 11, n_clusters=a.clusters, order=a.order)
 e = torch.from_numpy(e_np).cuda()
 lab = cluster_embeddings(e)
 torch.cuda.synchronize()
@@ -34,7 +35,7 @@ L.p2n_profile_collect(32, msum, cnt)
 L.p2n_profile_enable(0)
 k = {n: (msum[i] / max(cnt[i], 1)) * (cnt[i] // a.steps) for n, i in (("prep", 10), ("count", 11), ("link", 12))}
 flop_pass = 2.0 * a.n * a.n * (8 * ((a.d + 7) // 8))
-out = {"metric": "embedding clustering ms per scene", "n": a.n, "d": a.d, "ms": ms, "kernels_ms": k,
+out = {"metric": "embedding clustering ms per scene", "n": a.n, "d": a.d, "order": a.order, "ms": ms, "kernels_ms": k,
        "count_pass_tflops": flop_pass / (k["count"] * 1e-3) / 1e12, "link_pass_tflops": flop_pass / (k["link"] * 1e-3) / 1e12,
        "clusters": int(lab.max()), "noise": int((lab == 0).sum()), "stats": last_cluster_stats(a.n, a.d, 50)}
 if a.cpu_n:
