@@ -339,6 +339,11 @@ __device__ __forceinline__ float dpp_wave_shr1(float v, float fill) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One wave serves TWO queries: every lane measures its candidate against both with packed fp32
+// arithmetic (v_pk_add/mul_f32: same IEEE roundings as the scalar form, half the instructions), so the
+// LDS reads and the loop overhead are shared as well.  Each query keeps its own sorted list.
 __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__restrict__ query,
                                                                 const float *__restrict__ ref, int M, int N, int k,
                                                                 int32_t *__restrict__ idx, float *__restrict__ d2out,
@@ -346,18 +351,21 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__
     __shared__ __attribute__((aligned(16))) float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const long m = (long)blockIdx.x * KNN_WAVES + wave;
-    const bool active = m < M;
+    const long m0 = 2 * ((long)blockIdx.x * KNN_WAVES + wave);
+    const bool active = m0 < M;
+    const bool two = m0 + 1 < M;
     const float *P = ref + (long)b * N * 3;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
+    f32x2 qx = {0.f, 0.f}, qy = {0.f, 0.f}, qz = {0.f, 0.f};
     if (active) {
-        const float *q = query + ((long)b * M + m) * 3;
-        qx = q[0]; qy = q[1]; qz = q[2];
+        const float *q = query + ((long)b * M + m0) * 3;
+        qx[0] = q[0]; qy[0] = q[1]; qz[0] = q[2];
+        const float *q1 = two ? q + 3 : q;   // an odd tail repeats the query; its second list is not written
+        qx[1] = q1[0]; qy[1] = q1[1]; qz[1] = q1[2];
     }
     const float INF = __int_as_float(0x7f800000);
-    float ld = INF;   // lane l holds the l-th smallest distance seen so far
-    int li = -1;
-    float kth = INF;
+    float ld[2] = {INF, INF};   // lane l holds the l-th smallest distance seen so far, per query
+    int li[2] = {-1, -1};
+    float kth[2] = {INF, INF};
     for (int t0 = 0; t0 < N; t0 += KNN_TILE) {
         const int tn = min(KNN_TILE, N - t0);
         __syncthreads();
@@ -370,39 +378,52 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__
         if (!active) continue;
         for (int i0 = 0; i0 < tn; i0 += 64) {
             const int i = i0 + lane;
-            const float d = (i < tn) ? sqdist3(sx[i], sy[i], sz[i], qx, qy, qz) : INF;
-            unsigned long long mask = __ballot(d < kth);
-            while (mask) {
-                const int src = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
-                if (!(cd < kth)) continue;          // the k-th best tightened since the ballot
-                const int ci = t0 + i0 + src;
-                const bool gt = ld > cd;            // this lane's entry moves one rank down
-                const float pd = dpp_wave_shr1(ld, -1.f);
-                const int pi = __float_as_int(dpp_wave_shr1(__int_as_float(li), 0.f));
-                const bool pgt = pd > cd;
-                ld = gt ? (pgt ? pd : cd) : ld;
-                li = gt ? (pgt ? pi : ci) : li;
-                kth = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld), k - 1));
+            const bool in = i < tn;
+            const float x = in ? sx[i] : 0.f, y = in ? sy[i] : 0.f, z = in ? sz[i] : 0.f;
+            // ((dx*dx + dy*dy) + dz*dz), every operation rounded on its own (-ffp-contract=off), both queries at once
+            const f32x2 dx = f32x2{x, x} - qx, dy = f32x2{y, y} - qy, dz = f32x2{z, z} - qz;
+            const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float d = in ? dd[q] : INF;
+                unsigned long long mask = __ballot(d < kth[q]);
+                while (mask) {
+                    const int src = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
+                    if (!(cd < kth[q])) continue;          // the k-th best tightened since the ballot
+                    const int ci = t0 + i0 + src;
+                    const bool gt = ld[q] > cd;            // this lane's entry moves one rank down
+                    const float pd = dpp_wave_shr1(ld[q], -1.f);
+                    const int pi = __float_as_int(dpp_wave_shr1(__int_as_float(li[q]), 0.f));
+                    const bool pgt = pd > cd;
+                    ld[q] = gt ? (pgt ? pd : cd) : ld[q];
+                    li[q] = gt ? (pgt ? pi : ci) : li[q];
+                    kth[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld[q]), k - 1));
+                }
             }
         }
     }
-    if (active && lane < k) {
-        idx[((long)b * M + m) * k + lane] = li;
-        if (d2out) d2out[((long)b * M + m) * k + lane] = ld;
-    }
-    if (active && wout) {   // three-NN weights (k == 3): w_j = (1/(d2_j+1e-8)) / sum
-        const float r = __fdiv_rn(1.0f, __fadd_rn(ld, 1e-8f));
-        const float r0 = __shfl(r, 0), r1 = __shfl(r, 1), r2 = __shfl(r, 2);
-        const float s = __fadd_rn(__fadd_rn(r0, r1), r2);
-        if (lane < 3) wout[((long)b * M + m) * 3 + lane] = __fdiv_rn(r, s);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const long m = m0 + q;
+        if (!(active && (q == 0 || two))) continue;
+        if (lane < k) {
+            idx[((long)b * M + m) * k + lane] = li[q];
+            if (d2out) d2out[((long)b * M + m) * k + lane] = ld[q];
+        }
+        if (wout) {   // three-NN weights (k == 3): w_j = (1/(d2_j+1e-8)) / sum
+            const float r = __fdiv_rn(1.0f, __fadd_rn(ld[q], 1e-8f));
+            const float r0 = __shfl(r, 0), r1 = __shfl(r, 1), r2 = __shfl(r, 2);
+            const float s = __fadd_rn(__fadd_rn(r0, r1), r2);
+            if (lane < 3) wout[((long)b * M + m) * 3 + lane] = __fdiv_rn(r, s);
+        }
     }
 }
 
 static int knn_launch(const float *query, const float *ref, int B, int M, int N, int k, int32_t *idx, float *d2,
                       float *w, hipStream_t stream) {
-    const long blocks = ((long)M + KNN_WAVES - 1) / KNN_WAVES;
+    const long blocks = ((long)M + 2 * KNN_WAVES - 1) / (2 * KNN_WAVES);   // two queries per wave
     P2N_REQUIRE(B <= 65535, "p2n_knn: B > 65535");
     const int ps = p2n_prof_begin(P2N_K_KNN, stream);
     hipLaunchKernelGGL(p2n_knn_kernel, dim3((unsigned)blocks, B, 1), dim3(KNN_WAVES * 64), 0, stream, query, ref, M, N,
