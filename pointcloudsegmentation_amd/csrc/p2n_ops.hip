@@ -503,6 +503,159 @@ __global__ __launch_bounds__(256) void p2n_group_gather_v4_kernel(const float *_
         if (c0 + c < C) __builtin_nontemporal_store(v[c], reinterpret_cast<f32x4 *>(out + ((long)b * C + c0 + c) * MS + j));
 }
 
+// LDS-staged gather.  A divergent dword gather from global memory costs one L1 tag lookup per
+// distinct cache line (about one lane per clock per CU), which caps the two kernels above at
+// 35-44 % of the HBM rate.  When whole feature rows fit in LDS (CH * N floats <= 160 KiB) a
+// workgroup copies the rows of CH consecutive channels in once (they are contiguous in feat) and
+// gathers from LDS banks instead; HBM then sees one linear read of feat and linear 16-byte stores.
+// Grid: x = column split, y = channel chunk, z = cloud.  out has CC channels per cloud and this
+// call fills channels coff + [0, C) of it (CC = C, coff = 0 for the plain gather; the fused
+// set-abstraction grouping writes behind its three coordinate channels).
+// Needs N % 4 == 0, MS % 4 == 0 and 16-byte-aligned feat / idx / out.
+#define GL_MAX_LDS (160 * 1024)
+#define GL_U 4   // steps of the column walk whose indices are prefetched together
+template <int CH>
+__global__ __launch_bounds__(1024) void p2n_group_gather_lds_kernel(const float *__restrict__ feat,
+                                                                   const int32_t *__restrict__ idx, int C, int N,
+                                                                   long MS, float *__restrict__ out, int CC, int coff,
+                                                                   int quads_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    const int b = blockIdx.z, c0 = blockIdx.y * CH;
+    const int nch = C - c0 < CH ? C - c0 : CH;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(feat + ((long)b * C + c0) * N);
+    const int nv = nch * (N / 4);
+    for (int v = threadIdx.x; v < nv; v += blockDim.x) reinterpret_cast<f32x4 *>(rows)[v] = src[v];
+    __syncthreads();
+    const long nquad = MS / 4;
+    long q = (long)blockIdx.x * quads_per_split;
+    const long qend = q + quads_per_split < nquad ? q + quads_per_split : nquad;
+    const int32_t *ib = idx + (long)b * MS;
+    float *ob = out + ((long)b * CC + coff + c0) * MS;
+    // Rows of the output are M*ns floats apart -- a power of two for the usual shapes -- so workgroups
+    // that walk their rows in step would all be writing to the same few memory channels.  Every
+    // workgroup starts at its own phase of its column range and wraps around.  The walk is software
+    // pipelined: the indices of the next GL_U steps are in flight while this block's gathers and
+    // stores issue (one step is far shorter than an index load's latency).
+    const long q0 = q;
+    const int niter = (int)((qend - q0 + blockDim.x - 1) / blockDim.x);
+    if (niter == 0) return;
+    const int rot = (int)((blockIdx.x * 3 + blockIdx.y + (long)blockIdx.z * gridDim.y) * 7 % niter);
+    const i32x4 *iq = reinterpret_cast<const i32x4 *>(ib);
+    auto quad_of = [&](int k) -> long {   // k-th step of this workgroup's walk, -1 past the range
+        if (k >= niter) return -1;
+        int it = k + rot;
+        if (it >= niter) it -= niter;
+        const long qq = q0 + (long)it * blockDim.x + threadIdx.x;
+        return qq < qend ? qq : -1;
+    };
+    i32x4 ivn[GL_U];
+#pragma unroll
+    for (int u = 0; u < GL_U; ++u) {
+        const long qq = quad_of(u);
+        ivn[u] = qq >= 0 ? iq[qq] : i32x4{0, 0, 0, 0};
+    }
+    for (int k0 = 0; k0 < niter; k0 += GL_U) {
+        i32x4 ivc[GL_U];
+        long qc[GL_U];
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) {
+            ivc[u] = ivn[u];
+            qc[u] = quad_of(k0 + u);
+            const long qq = quad_of(k0 + GL_U + u);
+            ivn[u] = qq >= 0 ? iq[qq] : i32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) {
+            if (qc[u] < 0) continue;
+            int i[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) i[e] = clamp_idx(ivc[u][e], N);
+            f32x4 v[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[c][e] = rows[(c < nch ? c : 0) * N + i[e]];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < nch) __builtin_nontemporal_store(v[c], reinterpret_cast<f32x4 *>(ob + (long)c * MS) + qc[u]);
+        }
+    }
+}
+
+// Launch geometry of the LDS-staged kernels, from sweeps on MI355X (tools/sweep_gather.sh):
+//  - gather: few channels per workgroup (two rows, one when two do not fit half of the LDS) and
+//    1024 threads -- many small workgroups overlap their row loads with the others' stores;
+//  - interpolation: eight channels per workgroup, because the 96-byte neighbour table of
+//    a column quad is re-read once per channel chunk and is as large as six channels of output;
+//  - a column split that brings the grid to ~4 workgroups per CU.
+// P2N_GL_CH / P2N_GL_THREADS / P2N_GL_SPLIT override.
+struct GlGeom { int ch, threads, split; };
+static GlGeom gl_geometry(bool interp, int B, int C, long row_floats, long cols4) {
+    GlGeom g = {0, interp ? 512 : 1024, 1};
+    const long row_bytes = row_floats * 4;
+    const int ch_min = interp ? 4 : 1;   // the interpolation kernel reads channel quads from LDS
+    for (int ch = interp ? 8 : 2; ch >= ch_min; ch >>= 1)
+        if (ch * row_bytes <= GL_MAX_LDS / 2 || (ch == ch_min && ch * row_bytes <= GL_MAX_LDS)) { g.ch = ch; break; }
+    if (const char *e = getenv("P2N_GL_CH")) {
+        const int ch = atoi(e);
+        if ((ch == 1 || ch == 2 || ch == 4 || ch == 8 || ch == 16) && ch * row_bytes <= GL_MAX_LDS) g.ch = ch;
+    }
+    if (g.ch == 0) return g;
+    while (g.ch > ch_min && g.ch / 2 >= C) g.ch >>= 1;
+    if (const char *e = getenv("P2N_GL_THREADS")) {
+        const int t = atoi(e);
+        if (t == 256 || t == 512 || (t == 1024 && !interp)) g.threads = t;
+    }
+    const long groups = (long)B * ((C + g.ch - 1) / g.ch);
+    long split = (1024 + groups - 1) / groups;
+    const long max_split = cols4 / (4L * g.threads);   // keep >= 4 column quads per thread
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (const char *e = getenv("P2N_GL_SPLIT")) {
+        const int sp = atoi(e);
+        if (sp >= 1 && sp <= 65535) split = sp;
+    }
+    if (split > 65535) split = 65535;
+    g.split = (int)split;
+    return g;
+}
+
+template <typename K>
+static hipError_t gl_allow_lds(K kernel, size_t bytes) {
+    return bytes > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+                             : hipSuccess;
+}
+
+// Returns 1 when the LDS-staged kernel was launched, 0 when the shape does not qualify, < 0 on error.
+static int gather_lds_launch(const float *feat, const int32_t *idx, int B, int C, int N, long MS, float *out, int CC,
+                             int coff, hipStream_t stream) {
+    if (N % 4 || MS % 4 || ((((uintptr_t)feat | (uintptr_t)idx | (uintptr_t)out)) & 15)) return 0;
+    if (getenv("P2N_GL_OFF")) return 0;
+    const GlGeom g = gl_geometry(false, B, C, N, MS / 4);
+    if (g.ch == 0 || g.ch > 8) return 0;
+    const int quads_per_split = (int)((MS / 4 + g.split - 1) / g.split);
+    const dim3 grid((unsigned)g.split, (unsigned)((C + g.ch - 1) / g.ch), (unsigned)B);
+    const size_t lds = (size_t)g.ch * N * 4;
+    hipError_t e = hipSuccess;
+#define GL_LAUNCH(CHV)                                                                                              \
+    do {                                                                                                            \
+        e = gl_allow_lds(p2n_group_gather_lds_kernel<CHV>, lds);                                                    \
+        if (e == hipSuccess)                                                                                        \
+            hipLaunchKernelGGL(p2n_group_gather_lds_kernel<CHV>, grid, dim3(g.threads), lds, stream, feat, idx, C, N, MS, \
+                               out, CC, coff, quads_per_split);                                                     \
+    } while (0)
+    switch (g.ch) {
+        case 8: GL_LAUNCH(8); break;
+        case 4: GL_LAUNCH(4); break;
+        case 2: GL_LAUNCH(2); break;
+        default: GL_LAUNCH(1); break;
+    }
+#undef GL_LAUNCH
+    if (e != hipSuccess) { p2n_set_error("p2n gather: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1; }
+    return 1;
+}
+
 __global__ __launch_bounds__(256) void p2n_group_gather_bwd_kernel(const float *__restrict__ gout,
                                                                   const int32_t *__restrict__ idx, int C, int N,
                                                                   long MS, float *__restrict__ gfeat) {
@@ -550,7 +703,13 @@ extern "C" int p2n_sa_group(const float *xyz, const float *new_xyz, const float 
     P2N_REQUIRE(xyz && new_xyz && idx && out && (feat || C == 0), "p2n_sa_group: null pointer");
     P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH + 1 <= 65535, "p2n_sa_group: B or C too large");
     const long MS = (long)M * ns;
-    hipLaunchKernelGGL(p2n_sa_group_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH + 1, B), dim3(256), 0,
+    // feature channels through the LDS-staged gather when the shape qualifies; the same kernel then
+    // only writes the three relative-coordinate channels (grid y = 1)
+    int staged = 0;
+    if (C > 0) staged = gather_lds_launch(feat, idx, B, C, N, MS, out, C + 3, 3, (hipStream_t)stream);
+    if (staged < 0) return P2N_EHIP;
+    const int ychunks = staged ? 1 : (C + GG_CH - 1) / GG_CH + 1;
+    hipLaunchKernelGGL(p2n_sa_group_kernel, dim3((unsigned)((MS + 255) / 256), ychunks, B), dim3(256), 0,
                        (hipStream_t)stream, xyz, new_xyz, feat, idx, C, N, M, ns, out);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
@@ -563,8 +722,12 @@ extern "C" int p2n_group_gather(const float *feat, const int32_t *idx, int B, in
     if (B == 0 || C == 0 || MS == 0) return P2N_OK;
     P2N_REQUIRE(feat && idx && out, "p2n_group_gather: null pointer");
     P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_group_gather: B or C too large");
+    P2N_REQUIRE(MS / 4 <= 0x7fffffffL * 256, "p2n_group_gather: M*ns too large");
     const int ps = p2n_prof_begin(P2N_K_GATHER, (hipStream_t)stream);
-    if (MS % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) & 15) == 0)
+    const int staged = gather_lds_launch(feat, idx, B, C, N, MS, out, C, 0, (hipStream_t)stream);
+    if (staged < 0) return P2N_EHIP;
+    if (staged) {
+    } else if (MS % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) & 15) == 0)
         hipLaunchKernelGGL(p2n_group_gather_v4_kernel, dim3((unsigned)((MS / 4 + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
                            dim3(256), 0, (hipStream_t)stream, feat, idx, C, N, MS, out);
     else
@@ -644,6 +807,111 @@ __global__ __launch_bounds__(256) void p2n_three_interp_v4_kernel(const float *_
         }
 }
 
+// LDS-staged interpolation (same reasoning as p2n_group_gather_lds_kernel).  The rows of CH channels
+// of the known level are transposed into LDS as [point][CH], so that one ds_read_b128 fetches four
+// channels of a neighbour (a quarter of the LDS instructions of a dword gather -- the random bank
+// conflicts of those were what bounded the first version).  Every thread owns four unknown points and
+// keeps their 12 indices / weights in registers across the channels; the next step's table is
+// prefetched.  Same arithmetic order as the oracle: (w0*f0 + w1*f1) + w2*f2 without fma.
+// Needs m % 4 == 0, n % 4 == 0 and 16-byte-aligned feat / idx / weight / out.  CH = 4 or 8.
+template <int CH>
+__global__ __launch_bounds__(512) void p2n_three_interp_lds_kernel(const float *__restrict__ feat,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ w, int C, int m, int n,
+                                                                  float *__restrict__ out, int quads_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [m][CH]
+    const int b = blockIdx.z, c0 = blockIdx.y * CH;
+    const int nch = C - c0 < CH ? C - c0 : CH;
+    {   // fill: lane -> (channel c, point quad p4), c fastest; a lane reads 16 bytes of row c
+        const float *base = feat + ((long)b * C + c0) * m;
+        const int nv = CH * (m / 4);
+        for (int v = threadIdx.x; v < nv; v += blockDim.x) {
+            const int c = v % CH, p4 = v / CH;
+            const f32x4 val = c < nch ? reinterpret_cast<const f32x4 *>(base + (long)c * m)[p4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rows[(4 * p4 + e) * CH + c] = val[e];
+        }
+    }
+    __syncthreads();
+    const int nquad = n / 4;
+    const int q0 = blockIdx.x * quads_per_split;
+    const int qend = q0 + quads_per_split < nquad ? q0 + quads_per_split : nquad;
+    float *ob = out + ((long)b * C + c0) * n;
+    const int niter = (qend - q0 + (int)blockDim.x - 1) / (int)blockDim.x;
+    if (niter <= 0) return;
+    const int rot = (int)((blockIdx.x * 3 + blockIdx.y + (long)blockIdx.z * gridDim.y) * 7 % niter);
+    auto quad_of = [&](int k) -> int {
+        if (k >= niter) return -1;
+        int it = k + rot;
+        if (it >= niter) it -= niter;
+        const int qq = q0 + it * (int)blockDim.x + (int)threadIdx.x;
+        return qq < qend ? qq : -1;
+    };
+    i32x4 ivn[3];
+    f32x4 wvn[3];
+    auto fetch = [&](int qq) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            ivn[t] = qq >= 0 ? reinterpret_cast<const i32x4 *>(idx + ((long)b * n + 4L * qq) * 3)[t] : i32x4{0, 0, 0, 0};
+            wvn[t] = qq >= 0 ? reinterpret_cast<const f32x4 *>(w + ((long)b * n + 4L * qq) * 3)[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(quad_of(0));
+    for (int k = 0; k < niter; ++k) {
+        const int q = quad_of(k);
+        int id[12];
+        float ww[12];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { id[4 * t + e] = clamp_idx(ivn[t][e], m); ww[4 * t + e] = wvn[t][e]; }
+        fetch(quad_of(k + 1));
+        if (q < 0) continue;
+        f32x4 o[CH];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 *r0 = reinterpret_cast<const f32x4 *>(rows + id[3 * e] * CH);
+            const f32x4 *r1 = reinterpret_cast<const f32x4 *>(rows + id[3 * e + 1] * CH);
+            const f32x4 *r2 = reinterpret_cast<const f32x4 *>(rows + id[3 * e + 2] * CH);
+#pragma unroll
+            for (int h = 0; h < CH / 4; ++h) {
+                const f32x4 f0 = r0[h], f1 = r1[h], f2 = r2[h];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[4 * h + j][e] = __fadd_rn(__fadd_rn(__fmul_rn(ww[3 * e], f0[j]), __fmul_rn(ww[3 * e + 1], f1[j])),
+                                                __fmul_rn(ww[3 * e + 2], f2[j]));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (c < nch) __builtin_nontemporal_store(o[c], reinterpret_cast<f32x4 *>(ob + (long)c * n) + q);
+    }
+}
+
+static int interp_lds_launch(const float *feat, const int32_t *idx, const float *w, int B, int C, int m, int n,
+                             float *out, hipStream_t stream) {
+    if (m % 4 || n % 4 || ((((uintptr_t)feat | (uintptr_t)idx | (uintptr_t)w | (uintptr_t)out)) & 15)) return 0;
+    if (getenv("P2N_GL_OFF")) return 0;
+    const GlGeom g = gl_geometry(true, B, C, m, n / 4);
+    if (g.ch != 4 && g.ch != 8) return 0;
+    const int quads_per_split = (n / 4 + g.split - 1) / g.split;
+    const dim3 grid((unsigned)g.split, (unsigned)((C + g.ch - 1) / g.ch), (unsigned)B);
+    const size_t lds = (size_t)g.ch * m * 4;
+    hipError_t e = hipSuccess;
+#define GL_LAUNCH(CHV)                                                                                               \
+    do {                                                                                                             \
+        e = gl_allow_lds(p2n_three_interp_lds_kernel<CHV>, lds);                                                     \
+        if (e == hipSuccess)                                                                                         \
+            hipLaunchKernelGGL(p2n_three_interp_lds_kernel<CHV>, grid, dim3(g.threads), lds, stream, feat, idx, w, C, m, n, \
+                               out, quads_per_split);                                                                \
+    } while (0)
+    if (g.ch == 8) GL_LAUNCH(8);
+    else GL_LAUNCH(4);
+#undef GL_LAUNCH
+    if (e != hipSuccess) { p2n_set_error("p2n interpolate: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1; }
+    return 1;
+}
+
 __global__ __launch_bounds__(256) void p2n_three_interp_bwd_kernel(const float *__restrict__ gout,
                                                                   const int32_t *__restrict__ idx,
                                                                   const float *__restrict__ w, int C, int m, int n,
@@ -674,7 +942,10 @@ extern "C" int p2n_three_interpolate(const float *feat, const int32_t *idx, cons
     P2N_REQUIRE(feat && idx && weight && out, "p2n_three_interpolate: null pointer");
     P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_three_interpolate: B or C too large");
     const int ps = p2n_prof_begin(P2N_K_INTERP, (hipStream_t)stream);
-    if (n % 4 == 0 && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out) & 15) == 0)
+    const int staged = interp_lds_launch(feat, idx, weight, B, C, m, n, out, (hipStream_t)stream);
+    if (staged < 0) return P2N_EHIP;
+    if (staged) {
+    } else if (n % 4 == 0 && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out) & 15) == 0)
         hipLaunchKernelGGL(p2n_three_interp_v4_kernel, dim3((n / 4 + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
                            (hipStream_t)stream, feat, idx, weight, C, m, n, out);
     else

@@ -261,3 +261,70 @@ def test_three_interpolate_fwd_bwd():
         for j in range(3):
             np.add.at(g[b], (slice(None), idx[b, :, j]), gon[b] * w[b, :, j].astype(np.float64))
     np.testing.assert_allclose(ft.grad.cpu().numpy(), g, rtol=1e-4, atol=1e-5)
+
+
+# LDS-staged and global-gather variants of the same operators: shapes on both sides of the
+# launcher's conditions (row length / column count multiples of four, rows that fit LDS or not,
+# channel tails, several column splits) must give identical bits.
+@pytest.mark.parametrize("B,C,N,M,ns", [
+    (2, 19, 500, 40, 16),      # staged, channel tail
+    (2, 5, 501, 40, 16),       # N % 4 != 0: 16-byte global kernel
+    (1, 3, 64, 7, 3),          # M*ns % 4 != 0: scalar kernel
+    (3, 64, 8192, 256, 32),    # staged, two workgroups per CU, column splits
+    (1, 2, 40960, 128, 8),     # one 160 KiB row per workgroup
+    (1, 2, 50000, 128, 8),     # row does not fit LDS: global kernel
+    (2, 130, 2048, 64, 32),    # many channel chunks
+])
+def test_group_gather_variants(B, C, N, M, ns):
+    from oracle import oracle
+    from pointcloudsegmentation_amd import ops
+    rng = np.random.default_rng(C * N + M)
+    feat = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, size=(B, M, ns)).astype(np.int32)
+    idx[:, 0, 0] = 0
+    idx[:, -1, -1] = N - 1
+    want = oracle.group_gather(feat, idx)
+    out = ops.group_gather(torch.from_numpy(feat).cuda(), torch.from_numpy(idx).cuda())
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("B,C,m,n", [
+    (2, 21, 128, 700),         # staged, channel tail
+    (2, 7, 127, 700),          # m % 4 != 0
+    (1, 4, 64, 33),            # n % 4 != 0
+    (3, 256, 512, 2048),       # staged (feature-propagation level 1)
+    (2, 128, 2048, 8192),      # staged (feature-propagation level 2)
+    (1, 3, 50000, 4096),       # row does not fit LDS
+])
+def test_three_interpolate_variants(B, C, m, n):
+    from oracle import oracle
+    from pointcloudsegmentation_amd import ops
+    rng = np.random.default_rng(C + m + n)
+    feat = rng.standard_normal((B, C, m)).astype(np.float32)
+    idx = rng.integers(0, m, size=(B, n, 3)).astype(np.int32)
+    w = rng.random((B, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    want = oracle.three_interpolate(feat, idx, w)
+    out = ops.three_interpolate(torch.from_numpy(feat).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(w).cuda())
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("B,C,N,M,ns", [(2, 6, 512, 32, 16), (2, 6, 510, 32, 16), (1, 0, 256, 16, 8), (2, 67, 2048, 128, 32)])
+def test_sa_group_variants(B, C, N, M, ns):
+    rng = np.random.default_rng(N + C)
+    xyz = rng.standard_normal((B, N, 3)).astype(np.float32)
+    cen = rng.standard_normal((B, M, 3)).astype(np.float32)
+    feat = rng.standard_normal((B, C, N)).astype(np.float32) if C else None
+    idx = rng.integers(0, N, size=(B, M, ns)).astype(np.int32)
+    from pointcloudsegmentation_amd import _lib, runtime as _rt
+    tx, tc, ti = torch.from_numpy(xyz).cuda(), torch.from_numpy(cen).cuda(), torch.from_numpy(idx).cuda()
+    tf = None if feat is None else torch.from_numpy(feat).cuda()
+    out = torch.full((B, 3 + C, M, ns), float("nan"), device="cuda")
+    _lib.check(_lib.lib().p2n_sa_group(tx.data_ptr(), tc.data_ptr(), _rt.ptr(tf), ti.data_ptr(), B, C, N, M, ns,
+                                       out.data_ptr(), _rt.stream_handle(tx.device)), "p2n_sa_group")
+    want = np.empty((B, 3 + C, M, ns), np.float32)
+    for b in range(B):
+        want[b, :3] = (xyz[b][idx[b]] - cen[b][:, None, :]).transpose(2, 0, 1)
+        if C:
+            want[b, 3:] = feat[b][:, idx[b].reshape(-1)].reshape(C, M, ns)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)

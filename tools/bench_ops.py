@@ -15,6 +15,7 @@ HBM_PEAK_GBS = 8000.0
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--no-lidar", action="store_true")
+ap.add_argument("--only-gather", action="store_true", help="time only group gather and three-interpolate (geometry sweeps)")
 a = ap.parse_args()
 
 
@@ -48,7 +49,7 @@ for (name, M, ns, C, radius) in [("sa1", 2048, 32, 64, 0.1), ("sa2", 512, 32, 12
     src = xyz if name == "sa1" else cent
     n_src = src.size(1)
     lvl = {}
-    ms, idx = timed(lambda: ops.farthest_point_sample(src, M), a.iters)
+    ms, idx = timed(lambda: ops.farthest_point_sample(src, M), 1 if a.only_gather else a.iters)
     lvl["fps"] = entry(ms, B * (12 * n_src + 4 * M), "12*N xyz read + 4*M indices (state lives in registers; latency-bound, see us_per_sample)")
     lvl["fps"]["us_per_sample"] = 1e3 * ms / M
     cent_new = torch.gather(src, 1, idx.long()[..., None].expand(-1, -1, 3)).contiguous()
@@ -57,7 +58,7 @@ for (name, M, ns, C, radius) in [("sa1", 2048, 32, 64, 0.1), ("sa2", 512, 32, 12
     feat = torch.randn(B, C, n_src, device="cuda")
     ms, g = timed(lambda: ops.group_gather(feat, gidx), a.iters)
     lvl["group_gather"] = entry(ms, B * (4 * C * M * ns + 4 * M * ns + 4 * C * n_src), "4*C*M*ns written + 4*M*ns indices + 4*C*N features read once")
-    ms, k = timed(lambda: ops.knn(cent_new, src, 32, return_dist=False), a.iters)
+    ms, k = timed(lambda: ops.knn(cent_new, src, 32, return_dist=False), 1 if a.only_gather else a.iters)
     lvl["knn_k32"] = entry(ms, B * (12 * n_src + 12 * M + 4 * M * 32), "xyz + queries read, 4*M*k indices (VALU-bound: M*N distance tests)")
     out["levels"][name] = lvl
     cent = cent_new
@@ -82,4 +83,8 @@ if not a.no_lidar:
     lvl["knn_k32_16k_queries"] = entry(ms, 12 * 1_000_000 + 12 * 16384 + 4 * 16384 * 32, "VALU-bound: 1.6e10 distance tests")
     lvl["knn_k32_16k_queries"]["G_distance_tests_per_s"] = 16384 * 1e6 / (ms * 1e-3) / 1e9
     out["levels"]["lidar_1m"] = lvl
-print(json.dumps(out))
+if a.only_gather:
+    print(json.dumps({lv: {k: round(v["GB_per_s"]) for k, v in d.items() if k in ("group_gather", "three_interpolate")}
+                      for lv, d in out["levels"].items()}))
+else:
+    print(json.dumps(out))
