@@ -17,29 +17,30 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 typedef unsigned long long u64;
 
 // =========================================================================== FPS
-// A cluster of G workgroups (1024 threads each) owns one cloud; every thread keeps
-// PPT points (x, y, z, running min distance) in REGISTERS for the whole kernel, so
-// an iteration touches no memory except the winner exchange:
-//   thread argmax -> DPP/shuffle wave argmax -> LDS -> workgroup argmax  (1 barrier)
-//   G > 1: lane 0 publishes the workgroup's 64-bit key with one agent-scope atomic
-//   store into slot[it][g]; wave 0 polls the G slots of this iteration (zero = not
-//   yet written; slots are per iteration, so no tags or resets), reduces them and
-//   reads the winner's coordinates from xyz (immutable input).          (+1 barrier)
-// key = (bits(min_dist) << 32) | (0xFFFFFFFF - index): max key = farthest point,
-// lowest index on ties.  min_dist >= 0 so its bit pattern orders as an unsigned.
-#define FPS_THREADS 1024
-#define FPS_WAVES (FPS_THREADS / 64)
+// A cluster of G workgroups owns one cloud; every thread keeps PPT points (x, y, z, running min
+// distance) in REGISTERS for the whole kernel, so an iteration touches no memory except the
+// winner exchange.  What an iteration costs is instruction issue on one CU plus the exchange, so:
+//  * few, fat waves: 256 threads x up to 48 points (one wave per SIMD) -- the reductions are paid
+//    per wave, the distance updates per point;
+//  * distances for two points at a time (v_pk_add/mul_f32: same IEEE roundings as the scalar
+//    form), and the running argmax tracks only (distance, slot number); the winner's coordinates
+//    are read back from a copy of the chunk in LDS instead of being selected per point;
+//  * workgroup argmax: DPP maximum over each 16-lane row, then one 64-bit LDS atomic max per row
+//    into a key that rotates over three words (the word two iterations ahead is cleared behind
+//    the barrier, so no extra synchronisation) -- one barrier per iteration, every wave reads the
+//    winner with one ds_read_b64;
+//  * G > 1: four lanes of wave 0 publish {key, x, y, z} as four tagged 8-byte granules (one
+//    agent-scope atomic store each, tag = low key word, never zero) into slot[it][g]; wave 0 polls
+//    the G slots of this iteration (zero = not yet written; slots are per iteration, so no resets),
+//    reduces the keys by DPP and takes the winner's coordinates straight from its granules -- one
+//    fabric hop per iteration, bounded spin with a status word.
+// key = (bits(min_dist) << 32) | (0xFFFFFFFF - index): max key = farthest point, lowest index on
+// ties.  min_dist >= 0 so its bit pattern orders as an unsigned.
+// Large clouds that need more than 12,288 points per workgroup (B*G limited to 256 co-resident
+// workgroups, G <= 64) run 1024-thread workgroups with up to 20 points per thread; such a chunk
+// no longer fits LDS and the winner's coordinates come from global memory.
 #define FPS_SPIN_LIMIT (1 << 22)
-#define FPS_MAX_PPT 20   // 24 points per thread spill past the 128-VGPR budget of a 1024-thread workgroup
-
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const u64 t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
-}
+#define FPS_LDS_POINTS 12288   // chunk that fits LDS as xyz (147,456 B)
 
 // DPP reductions on 32-bit unsigned values: one VALU instruction per step, no LDS.
 #define DPP_MAX_STEP(v, ctrl, rmask, keep)                                                            \
@@ -65,18 +66,29 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 64-bit LDS atomic max without a return value, as the instruction itself: written through
+// atomicMax the compiler serialises the active lanes in a scalar loop first (uniform address).
+// The wait makes the update visible to the barrier that follows.
+__device__ __forceinline__ void lds_max_u64(u64 *p, u64 v) {
+    const unsigned off = (unsigned)(uintptr_t)p;   // low half of a flat LDS address = the LDS offset
+    asm volatile("ds_max_u64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(off), "v"(v) : "memory");
+}
+
 struct FpsArgs {
     const float *xyz;   // (B,N,3)
     int32_t *idx;       // (B,M)
-    u64 *slots;         // [clouds of this launch][M][G], zeroed per launch (G > 1 only)
+    u64 *slots;         // [clouds of this launch][M][G][4], zeroed per launch (G > 1 only)
     int *status;        // 0 ok, 1 = exchange timed out
     int N, M, G, chunk, start_idx, b0;
 };
 
-template <int PPT>
-__global__ __launch_bounds__(FPS_THREADS) void p2n_fps_kernel(FpsArgs A) {
-    __shared__ u64 wkey[2][FPS_WAVES];
-    __shared__ float wxyz[2][FPS_WAVES][4];
+template <int T, int PPT, bool LDSXYZ>
+__global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
+    static_assert(PPT % 2 == 0, "points are processed in pairs");
+    extern __shared__ __attribute__((aligned(16))) float lxyz[];   // LDSXYZ: this workgroup's chunk, [point][3]
+    __shared__ u64 wkey[3];
     __shared__ float bc[2][4];   // broadcast of the iteration's winner (G > 1)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = A.b0 + blockIdx.x / A.G, g = blockIdx.x % A.G;
@@ -86,89 +98,126 @@ __global__ __launch_bounds__(FPS_THREADS) void p2n_fps_kernel(FpsArgs A) {
     if (nloc > A.chunk) nloc = A.chunk;
     if (nloc < 0) nloc = 0;
 
-    // Slot s of thread t is point base + t + 1024*s.  Slots past the chunk hold the origin
-    // with running minimum 0: min(0, d) stays 0, and their (virtual) index is larger than
-    // every real index of the cloud, so they lose every tie against a real point and need
-    // no special casing in the loop below.
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    // Slot s of thread t is point base + t + T*s.  Slots past the chunk hold the origin with running
+    // minimum 0: min(0, d) stays 0, and the workgroup's first real point has a lower index, so they
+    // lose every tie and need no special casing in the loop below.
+    f32x2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], md[PPT / 2];
+    if (LDSXYZ) {   // one coalesced copy of the chunk into LDS, registers filled from there
+        for (int i = t; i < nloc * 3; i += T) lxyz[i] = P[(long)base * 3 + i];
+    }
+    if (t < 3) wkey[t] = 0ull;
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
-        const int i = t + FPS_THREADS * s;
+        const int i = t + T * s;
         const bool ok = i < nloc;
-        px[s] = ok ? P[(long)(base + i) * 3 + 0] : 0.f;
-        py[s] = ok ? P[(long)(base + i) * 3 + 1] : 0.f;
-        pz[s] = ok ? P[(long)(base + i) * 3 + 2] : 0.f;
-        md[s] = ok ? __int_as_float(0x7f800000) : 0.f;
+        const float *src = LDSXYZ ? lxyz + i * 3 : P + (long)(base + i) * 3;
+        px[s / 2][s & 1] = ok ? src[0] : 0.f;
+        py[s / 2][s & 1] = ok ? src[1] : 0.f;
+        pz[s / 2][s & 1] = ok ? src[2] : 0.f;
+        md[s / 2][s & 1] = ok ? __int_as_float(0x7f800000) : 0.f;
     }
+
     int cur = A.start_idx;
     float cx = P[(long)cur * 3 + 0], cy = P[(long)cur * 3 + 1], cz = P[(long)cur * 3 + 2];
     bool dead = false;
     const unsigned inv0 = 0xFFFFFFFFu - (unsigned)(base + t);
+    int kb = 0;   // it % 3
 
     for (int it = 0; it < A.M; ++it) {
         if (g == 0 && t == 0) A.idx[(long)b * A.M + it] = cur;
         if (it + 1 == A.M) break;
-        // ---- update running minima, thread-local argmax (first maximum wins: indices ascend with s)
-        unsigned invb = inv0;
-        asm volatile("" : "+v"(invb));   // keep the per-slot index arithmetic inside the iteration (registers)
-        float best, bx = px[0], by = py[0], bz = pz[0];
-        unsigned binv = invb;
-        {
-            const float d = sqdist3(px[0], py[0], pz[0], cx, cy, cz);
-            best = md[0] = fminf(md[0], d);
-        }
+        // ---- update running minima (v_min_f32 as the instruction: fminf() would canonicalise its
+        // operands first, one more VALU op per point)
+        const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+        u64 tk[PPT / 2];   // per pair: (distance bits << 32) | (63 - slot): the maximum is the farthest, lowest slot
 #pragma unroll
-        for (int s = 1; s < PPT; ++s) {
-            const float d = sqdist3(px[s], py[s], pz[s], cx, cy, cz);
-            const float m = fminf(md[s], d);
-            md[s] = m;
-            const bool take = m > best;
-            best = take ? m : best;
-            binv = take ? invb - (unsigned)(FPS_THREADS * s) : binv;
-            bx = take ? px[s] : bx;
-            by = take ? py[s] : by;
-            bz = take ? pz[s] : bz;
+        for (int p = 0; p < PPT / 2; ++p) {
+            const f32x2 dx = px[p] - c2x, dy = py[p] - c2y, dz = pz[p] - c2z;
+            const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+            float m0, m1;
+            asm("v_min_f32 %0, %1, %2" : "=v"(m0) : "v"(md[p][0]), "v"(dd[0]));
+            asm("v_min_f32 %0, %1, %2" : "=v"(m1) : "v"(md[p][1]), "v"(dd[1]));
+            md[p][0] = m0;
+            md[p][1] = m1;
+            const bool take = m1 > m0;   // first maximum wins: slots (and indices) ascend
+            tk[p] = ((u64)__float_as_uint(take ? m1 : m0) << 32) | (unsigned)(take ? 62 - 2 * p : 63 - 2 * p);
         }
-        // wave argmax on the 64-bit key (distance bits, inverted index) as two 32-bit DPP maxima
+        // ---- thread-local argmax as a tournament of 64-bit keys (independent compares instead of
+        // one chain of PPT dependent ones)
+#pragma unroll
+        for (int w = 1; w < PPT / 2; w <<= 1)
+#pragma unroll
+            for (int p = 0; p < PPT / 2; ++p)   // constant trip count so that every index is a constant
+                if (p % (2 * w) == 0 && p + w < PPT / 2) tk[p] = tk[p + w] > tk[p] ? tk[p + w] : tk[p];
+        const float best = __uint_as_float((unsigned)(tk[0] >> 32));
+        const int bs = 63 - (int)(unsigned)(tk[0] & 0xFFFFFFFFull);
+        // ---- workgroup argmax on the 64-bit key: row maxima by DPP, rows by LDS atomic max
         const unsigned hi = __float_as_uint(best);
-        const unsigned whi = wave_max_u32(hi);
-        const unsigned wlo = wave_max_u32(hi == whi ? binv : 0u);
-        const int buf = it & 1;
-        if (hi == whi && binv == wlo) {   // keys are unique within a cloud: exactly one lane
-            wkey[buf][wave] = ((u64)whi << 32) | wlo;
-            wxyz[buf][wave][0] = bx; wxyz[buf][wave][1] = by; wxyz[buf][wave][2] = bz;
-        }
+        const unsigned binv = inv0 - (unsigned)(T * bs);
+        const unsigned rhi = row16_max_u32(hi);
+        const unsigned rlo = row16_max_u32(hi == rhi ? binv : 0u);
+        if ((lane & 15) == 0) lds_max_u64(&wkey[kb], ((u64)rhi << 32) | rlo);
         __syncthreads();
-        // workgroup argmax: the 16 wave keys sit one per lane in every 16-lane row
-        const u64 mine = wkey[buf][lane & (FPS_WAVES - 1)];
-        const unsigned mhi = (unsigned)(mine >> 32), mlo = (unsigned)mine;
-        const unsigned khi = row16_max_u32(mhi);
-        const unsigned klo = row16_max_u32(mhi == khi ? mlo : 0u);
-        const u64 k = ((u64)khi << 32) | klo;
-        const int kw = __builtin_ctzll(__ballot(mhi == khi && mlo == klo)) & (FPS_WAVES - 1);
+        const u64 k = wkey[kb];
+        const int kclr = kb == 0 ? 2 : kb - 1;   // (it + 2) % 3: last read before this barrier, next used behind the next one
+        if (t == 0) wkey[kclr] = 0ull;
+        kb = kb == 2 ? 0 : kb + 1;
+        const int li = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));   // this workgroup's winner
         if (A.G == 1) {
-            cur = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));
-            cx = wxyz[buf][kw][0]; cy = wxyz[buf][kw][1]; cz = wxyz[buf][kw][2];
+            cur = li;
+            if (LDSXYZ) {
+                cx = lxyz[(li - base) * 3 + 0]; cy = lxyz[(li - base) * 3 + 1]; cz = lxyz[(li - base) * 3 + 2];
+            } else {
+                cx = P[(long)li * 3 + 0]; cy = P[(long)li * 3 + 1]; cz = P[(long)li * 3 + 2];
+            }
         } else {
+            const int buf = it & 1;
             if (wave == 0) {
-                u64 *slot = A.slots + ((long)(b - A.b0) * A.M + it) * A.G;
-                if (lane == 0) __hip_atomic_store(slot + g, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u64 v = 0;
+                u64 *slot = A.slots + (((long)(b - A.b0) * A.M + it) * A.G) * 4;
+                if (lane < 4) {
+                    u64 payload = k;
+                    if (lane > 0) {
+                        // a workgroup without real points (li outside its chunk) publishes zeros with its losing key
+                        const bool real = li >= base && li < base + nloc;
+                        const float c = !real ? 0.f : (LDSXYZ ? lxyz[(li - base) * 3 + lane - 1] : P[(long)li * 3 + lane - 1]);
+                        payload = ((k & 0xFFFFFFFFull) << 32) | (u64)__float_as_uint(c);
+                    }
+                    __hip_atomic_store(slot + g * 4 + lane, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                u64 v0 = 0, v1 = 0, v2 = 0, v3 = 0;
                 int spins = 0;
                 bool ok;
                 for (;;) {
                     // lanes >= G read nothing and count as ready; G <= 64
-                    v = (lane < A.G) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull;
-                    ok = __all(v != 0ull);
+                    bool ready = true;
+                    if (lane < A.G) {
+                        const u64 *sl = slot + lane * 4;
+                        v0 = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v1 = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v2 = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v3 = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = v0 != 0ull && (v1 >> 32) != 0ull && (v2 >> 32) != 0ull && (v3 >> 32) != 0ull;
+                    }
+                    ok = __all(ready);
                     if (ok || ++spins > FPS_SPIN_LIMIT) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (lane >= A.G) v = 0;
-                const u64 win = wave_max_u64(v);
-                int widx = (int)(0xFFFFFFFFu - (unsigned)(win & 0xFFFFFFFFu));
-                if (!ok || widx < 0 || widx >= A.N) widx = -1;
-                if (lane < 3) bc[buf][lane] = widx >= 0 ? P[(long)widx * 3 + lane] : 0.f;
-                if (lane == 3) bc[buf][3] = __int_as_float(widx);
+                const bool mine = lane < A.G;
+                const unsigned khi = mine ? (unsigned)(v0 >> 32) : 0u, klo = mine ? (unsigned)v0 : 0u;
+                const unsigned whi = wave_max_u32(khi);
+                const unsigned wlo = wave_max_u32(khi == whi ? klo : 0u);
+                const u64 wmask = __ballot(mine && khi == whi && klo == wlo);
+                const int wl = wmask ? __builtin_ctzll(wmask) : 0;
+                int widx = (int)(0xFFFFFFFFu - wlo);
+                if (!ok || !wmask || widx < 0 || widx >= A.N) widx = -1;
+                const float wx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)v1, wl));
+                const float wy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)v2, wl));
+                const float wz = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)v3, wl));
+                if (lane == 0) {
+                    bc[buf][0] = wx; bc[buf][1] = wy; bc[buf][2] = wz;
+                    bc[buf][3] = __int_as_float(widx);
+                }
             }
             __syncthreads();
             cur = __float_as_int(bc[buf][3]);
@@ -179,37 +228,76 @@ __global__ __launch_bounds__(FPS_THREADS) void p2n_fps_kernel(FpsArgs A) {
     if (dead && t == 0) atomicExch(A.status, 1);
 }
 
-static int fps_pick_g(int B, int N) {
-    if (const char *e = getenv("P2N_FPS_G")) {   // tuning override (tools/fps_sweep.py)
-        const int g = atoi(e);
-        if (g >= 1 && g <= 64 && (long)g * FPS_THREADS * FPS_MAX_PPT >= N && (long)g * B <= 256) return g;
-    }
-    // one workgroup holds up to FPS_MAX_PPT points per thread; prefer ~8 per thread when the
-    // chip has spare CUs, but all B*G workgroups must be co-resident (<= 256)
-    const int cap = FPS_THREADS * FPS_MAX_PPT;
-    int gmin = (N + cap - 1) / cap;
-    int gwant = (N + FPS_THREADS * 8 - 1) / (FPS_THREADS * 8);
-    int gmax = 256 / (B < 256 ? B : 256);
+// Launch plan: workgroups per cloud, threads, points per thread.
+struct FpsPlan { int G, T, ppt; };
+static const int kFpsPpt256[] = {2, 4, 8, 16, 24, 32, 40, 48};
+static const int kFpsPpt1024[] = {16, 20};   // only chunks beyond FPS_LDS_POINTS get here
+static FpsPlan fps_plan(int B, int N) {
+    FpsPlan p = {0, 256, 0};
+    int gmax = 256 / (B < 256 ? B : 256);   // all B*G workgroups must be co-resident
     if (gmax < 1) gmax = 1;
     if (gmax > 64) gmax = 64;
-    int G = gwant;
-    if (G > gmax) G = gmax;
-    if (G < gmin) G = gmin;
-    if (N <= cap && G > 1 && N <= FPS_THREADS * 12) G = 1;   // small clouds: the exchange costs more than it saves
-    return G;
+    int G;
+    const int gmin256 = (N + FPS_LDS_POINTS - 1) / FPS_LDS_POINTS;
+    if (gmin256 <= gmax) {
+        // fits 256-thread workgroups.  One workgroup whenever the cloud fits it (the exchange costs
+        // more than the distance updates it saves); otherwise ~4096 points per workgroup.
+        G = gmin256;
+        if (G > 1) {
+            G = (N + 4095) / 4096;
+            if (G > gmax) G = gmax;
+        }
+        p.T = 256;
+    } else {
+        const int cap = 1024 * 20;
+        G = (N + cap - 1) / cap;
+        if (G <= gmax) {   // spare CUs: ~8 points per thread
+            int gw = (N + 8191) / 8192;
+            if (gw > gmax) gw = gmax;
+            if (gw > G) G = gw;
+        }
+        p.T = 1024;
+    }
+    if (const char *e = getenv("P2N_FPS_G")) {   // tuning override (tools/fps_sweep.py)
+        const int g = atoi(e);
+        if (g >= 1 && g <= gmax) {
+            const int chunk = (N + g - 1) / g;
+            if (chunk <= FPS_LDS_POINTS) { G = g; p.T = 256; }
+            else if (chunk <= 1024 * 20 && gmin256 > gmax) { G = g; p.T = 1024; }
+        }
+    }
+    if (G > gmax) return p;   // does not fit one launch: p.G stays 0
+    const int chunk = (N + G - 1) / G;
+    const int need = (chunk + p.T - 1) / p.T;
+    const int *tab = p.T == 256 ? kFpsPpt256 : kFpsPpt1024;
+    const int ntab = p.T == 256 ? 8 : 2;
+    for (int i = 0; i < ntab; ++i)
+        if (tab[i] >= need) { p.ppt = tab[i]; break; }
+    if (p.ppt == 0) return p;
+    p.G = G;
+    return p;
 }
 
 extern "C" size_t p2n_fps_workspace_bytes(int B, int N, int M) {
     if (B < 1 || N < 1 || M < 1) return 16;
-    const int G = fps_pick_g(1, N);   // the largest G any sub-batch can use
-    return 16 + (G > 1 ? sizeof(u64) * (size_t)B * M * 64 : 0);
+    // slots of the largest sub-batch: at most 64 workgroups per cloud, 32 bytes each per sample
+    const FpsPlan p = fps_plan(1, N);
+    const int gmax = p.G > 1 ? 64 : 1;
+    return 16 + (gmax > 1 ? sizeof(u64) * 4 * (size_t)B * M * gmax : 0);
 }
 
-template <int PPT>
-static void fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
+template <int T, int PPT, bool LDSXYZ>
+static hipError_t fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
+    const size_t lds = LDSXYZ ? (size_t)a.chunk * 12 : 0;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_fps_kernel<T, PPT, LDSXYZ>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     const int ps = p2n_prof_begin(P2N_K_FPS, s);
-    hipLaunchKernelGGL(p2n_fps_kernel<PPT>, dim3(nb * a.G), dim3(FPS_THREADS), 0, s, a);
+    hipLaunchKernelGGL((p2n_fps_kernel<T, PPT, LDSXYZ>), dim3(nb * a.G), dim3(T), lds, s, a);
     p2n_prof_end(ps, s);
+    return hipGetLastError();
 }
 
 extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, void *workspace,
@@ -224,36 +312,43 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         p2n_set_error("p2n_fps: workspace %zu bytes < required %zu", workspace_bytes, need);
         return P2N_EWORKSPACE;
     }
-    const int cap = FPS_THREADS * FPS_MAX_PPT;
     // sub-batches so that every launch's workgroups are co-resident (<= 256)
     int done = 0;
     P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));
     while (done < B) {
         int nb = B - done;
         if (nb > 256) nb = 256;
-        int G = fps_pick_g(nb, N);
-        if ((long)G * cap < N) {   // cloud too large to be resident with this many clouds in flight
-            nb = 256 / ((N + cap - 1) / cap);
-            P2N_REQUIRE(nb >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 256 * cap);
-            if (nb > B - done) nb = B - done;
-            G = fps_pick_g(nb, N);
+        FpsPlan p = fps_plan(nb, N);
+        while (p.G == 0 && nb > 1) {   // cloud too large to be resident with this many clouds in flight
+            nb = nb / 2;
+            p = fps_plan(nb, N);
         }
-        P2N_REQUIRE(G <= 64 && (long)G * cap >= N, "p2n_fps: N=%d needs more than 64 workgroups per cloud", N);
+        P2N_REQUIRE(p.G >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 64 * 1024 * 20);
         FpsArgs a;
         a.xyz = xyz; a.idx = idx; a.status = (int *)workspace;
         a.slots = (u64 *)((char *)workspace + 16);
-        a.N = N; a.M = M; a.G = G; a.chunk = (N + G - 1) / G; a.start_idx = start_idx; a.b0 = done;
-        if (G > 1)   // launches run in stream order, so they can share the slot region
-            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 16, 0, sizeof(u64) * (size_t)nb * M * G, stream));
-        const int ppt = (a.chunk + FPS_THREADS - 1) / FPS_THREADS;
-        if (ppt <= 1) fps_launch<1>(a, nb, stream);
-        else if (ppt <= 2) fps_launch<2>(a, nb, stream);
-        else if (ppt <= 4) fps_launch<4>(a, nb, stream);
-        else if (ppt <= 8) fps_launch<8>(a, nb, stream);
-        else if (ppt <= 12) fps_launch<12>(a, nb, stream);
-        else if (ppt <= 16) fps_launch<16>(a, nb, stream);
-        else fps_launch<20>(a, nb, stream);
-        P2N_CHECK_HIP(hipGetLastError());
+        a.N = N; a.M = M; a.G = p.G; a.chunk = (N + p.G - 1) / p.G; a.start_idx = start_idx; a.b0 = done;
+        if (p.G > 1)   // launches run in stream order, so they can share the slot region
+            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 16, 0, sizeof(u64) * 4 * (size_t)nb * M * p.G, stream));
+        hipError_t e = hipErrorInvalidValue;
+        if (p.T == 256) {
+            switch (p.ppt) {
+                case 2: e = fps_launch<256, 2, true>(a, nb, stream); break;
+                case 4: e = fps_launch<256, 4, true>(a, nb, stream); break;
+                case 8: e = fps_launch<256, 8, true>(a, nb, stream); break;
+                case 16: e = fps_launch<256, 16, true>(a, nb, stream); break;
+                case 24: e = fps_launch<256, 24, true>(a, nb, stream); break;
+                case 32: e = fps_launch<256, 32, true>(a, nb, stream); break;
+                case 40: e = fps_launch<256, 40, true>(a, nb, stream); break;
+                case 48: e = fps_launch<256, 48, true>(a, nb, stream); break;
+            }
+        } else {
+            switch (p.ppt) {
+                case 16: e = fps_launch<1024, 16, false>(a, nb, stream); break;
+                case 20: e = fps_launch<1024, 20, false>(a, nb, stream); break;
+            }
+        }
+        P2N_CHECK_HIP(e);
         done += nb;
     }
     return P2N_OK;
@@ -522,10 +617,6 @@ __global__ __launch_bounds__(1024) void p2n_group_gather_lds_kernel(const float 
     extern __shared__ __attribute__((aligned(16))) float rows[];
     const int b = blockIdx.z, c0 = blockIdx.y * CH;
     const int nch = C - c0 < CH ? C - c0 : CH;
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(feat + ((long)b * C + c0) * N);
-    const int nv = nch * (N / 4);
-    for (int v = threadIdx.x; v < nv; v += blockDim.x) reinterpret_cast<f32x4 *>(rows)[v] = src[v];
-    __syncthreads();
     const long nquad = MS / 4;
     long q = (long)blockIdx.x * quads_per_split;
     const long qend = q + quads_per_split < nquad ? q + quads_per_split : nquad;
@@ -538,8 +629,7 @@ __global__ __launch_bounds__(1024) void p2n_group_gather_lds_kernel(const float 
     // stores issue (one step is far shorter than an index load's latency).
     const long q0 = q;
     const int niter = (int)((qend - q0 + blockDim.x - 1) / blockDim.x);
-    if (niter == 0) return;
-    const int rot = (int)((blockIdx.x * 3 + blockIdx.y + (long)blockIdx.z * gridDim.y) * 7 % niter);
+    const int rot = niter > 0 ? (int)((blockIdx.x * 3 + blockIdx.y + (long)blockIdx.z * gridDim.y) * 7 % niter) : 0;
     const i32x4 *iq = reinterpret_cast<const i32x4 *>(ib);
     auto quad_of = [&](int k) -> long {   // k-th step of this workgroup's walk, -1 past the range
         if (k >= niter) return -1;
@@ -554,6 +644,11 @@ __global__ __launch_bounds__(1024) void p2n_group_gather_lds_kernel(const float 
         const long qq = quad_of(u);
         ivn[u] = qq >= 0 ? iq[qq] : i32x4{0, 0, 0, 0};
     }
+    // the row copy goes behind the first index loads, so both latencies overlap
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(feat + ((long)b * C + c0) * N);
+    const int nv = nch * (N / 4);
+    for (int v = threadIdx.x; v < nv; v += blockDim.x) reinterpret_cast<f32x4 *>(rows)[v] = src[v];
+    __syncthreads();
     for (int k0 = 0; k0 < niter; k0 += GL_U) {
         i32x4 ivc[GL_U];
         long qc[GL_U];
@@ -822,24 +917,12 @@ __global__ __launch_bounds__(512) void p2n_three_interp_lds_kernel(const float *
     extern __shared__ __attribute__((aligned(16))) float rows[];   // [m][CH]
     const int b = blockIdx.z, c0 = blockIdx.y * CH;
     const int nch = C - c0 < CH ? C - c0 : CH;
-    {   // fill: lane -> (channel c, point quad p4), c fastest; a lane reads 16 bytes of row c
-        const float *base = feat + ((long)b * C + c0) * m;
-        const int nv = CH * (m / 4);
-        for (int v = threadIdx.x; v < nv; v += blockDim.x) {
-            const int c = v % CH, p4 = v / CH;
-            const f32x4 val = c < nch ? reinterpret_cast<const f32x4 *>(base + (long)c * m)[p4] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rows[(4 * p4 + e) * CH + c] = val[e];
-        }
-    }
-    __syncthreads();
     const int nquad = n / 4;
     const int q0 = blockIdx.x * quads_per_split;
     const int qend = q0 + quads_per_split < nquad ? q0 + quads_per_split : nquad;
     float *ob = out + ((long)b * C + c0) * n;
     const int niter = (qend - q0 + (int)blockDim.x - 1) / (int)blockDim.x;
-    if (niter <= 0) return;
-    const int rot = (int)((blockIdx.x * 3 + blockIdx.y + (long)blockIdx.z * gridDim.y) * 7 % niter);
+    const int rot = niter > 0 ? (int)((blockIdx.x * 3 + blockIdx.y + (long)blockIdx.z * gridDim.y) * 7 % niter) : 0;
     auto quad_of = [&](int k) -> int {
         if (k >= niter) return -1;
         int it = k + rot;
@@ -857,6 +940,18 @@ __global__ __launch_bounds__(512) void p2n_three_interp_lds_kernel(const float *
         }
     };
     fetch(quad_of(0));
+    // the transposing row copy goes behind the first table loads, so both latencies overlap
+    {   // fill: lane -> (channel c, point quad p4), c fastest; a lane reads 16 bytes of row c
+        const float *base = feat + ((long)b * C + c0) * m;
+        const int nv = CH * (m / 4);
+        for (int v = threadIdx.x; v < nv; v += blockDim.x) {
+            const int c = v % CH, p4 = v / CH;
+            const f32x4 val = c < nch ? reinterpret_cast<const f32x4 *>(base + (long)c * m)[p4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rows[(4 * p4 + e) * CH + c] = val[e];
+        }
+    }
+    __syncthreads();
     for (int k = 0; k < niter; ++k) {
         const int q = quad_of(k);
         int id[12];

@@ -25,7 +25,8 @@ def _grid_cloud(B, side):
 
 # ------------------------------------------------------------------ FPS
 @pytest.mark.parametrize("B,N,M,start", [(1, 1, 1, 0), (2, 5, 5, 3), (3, 1000, 64, 0), (2, 1024, 256, 17),
-                                         (16, 8192, 512, 0), (2, 13000, 300, 5), (1, 20480, 200, 0)])
+                                         (16, 8192, 512, 0), (2, 13000, 300, 5), (1, 20480, 200, 0),
+                                         (2, 12288, 200, 1), (1, 12289, 200, 12288), (2, 3, 3, 2), (1, 600, 600, 0)])
 def test_fps_single_workgroup(B, N, M, start):
     from oracle import oracle
     from pointcloudsegmentation_amd import ops
@@ -35,7 +36,10 @@ def test_fps_single_workgroup(B, N, M, start):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("B,N,M", [(1, 40000, 400), (2, 40000, 300), (1, 150000, 200), (3, 25000, 100)])
+@pytest.mark.parametrize("B,N,M", [(1, 40000, 400), (2, 40000, 300), (1, 150000, 200), (3, 25000, 100),
+                                   (128, 40000, 12),     # two 1024-thread workgroups per cloud, coordinates from global memory
+                                   (40, 30000, 40),      # six 256-thread workgroups per cloud (co-residency caps G)
+                                   (1, 700001, 64)])     # 64 workgroups x 20 points per thread
 def test_fps_multi_workgroup(B, N, M):
     """Clouds too large for one workgroup's registers: cluster of workgroups with a
     per-iteration winner exchange."""

@@ -37,6 +37,19 @@ def timed(fn, iters):
     return sum(ms) / iters, r
 
 
+def fill_ms(nbytes, iters=20):
+    """A plain device fill of the same number of bytes: what the memory system gives a pure
+    streaming write of this size (small launches never reach the 8 TB/s figure)."""
+    buf = torch.empty(int(nbytes) // 4, device="cuda")
+    buf.fill_(0.0); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        buf.fill_(0.0)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def entry(ms, nbytes, note):
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"ms": ms, "algorithmic_MB": nbytes / 1e6, "GB_per_s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes": note}
@@ -58,6 +71,7 @@ for (name, M, ns, C, radius) in [("sa1", 2048, 32, 64, 0.1), ("sa2", 512, 32, 12
     feat = torch.randn(B, C, n_src, device="cuda")
     ms, g = timed(lambda: ops.group_gather(feat, gidx), a.iters)
     lvl["group_gather"] = entry(ms, B * (4 * C * M * ns + 4 * M * ns + 4 * C * n_src), "4*C*M*ns written + 4*M*ns indices + 4*C*N features read once")
+    lvl["group_gather"]["fill_of_same_bytes_ms"] = fill_ms(B * (4 * C * M * ns + 4 * M * ns + 4 * C * n_src))
     ms, k = timed(lambda: ops.knn(cent_new, src, 32, return_dist=False), 1 if a.only_gather else a.iters)
     lvl["knn_k32"] = entry(ms, B * (12 * n_src + 12 * M + 4 * M * 32), "xyz + queries read, 4*M*k indices (VALU-bound: M*N distance tests)")
     out["levels"][name] = lvl
@@ -71,6 +85,7 @@ for (name, n, m, C) in [("fp_512_to_2048", 2048, 512, 256), ("fp_2048_to_8192", 
     feat = torch.randn(B, C, m, device="cuda")
     ms, o = timed(lambda: ops.three_interpolate(feat, idx3, w3), a.iters)
     lvl["three_interpolate"] = entry(ms, B * (4 * C * n + 24 * n + 4 * C * m), "4*C*n written + 24*n idx/weight + 4*C*m features read once")
+    lvl["three_interpolate"]["fill_of_same_bytes_ms"] = fill_ms(B * (4 * C * n + 24 * n + 4 * C * m))
     out["levels"][name] = lvl
 if not a.no_lidar:
     big = torch.from_numpy(np.ascontiguousarray(make_batch(1, 1_000_000, 4, "lidar")[:, :, :3])).cuda()

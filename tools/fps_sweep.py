@@ -18,8 +18,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps({"B": B, "N": N, "M": M, "G": os.environ.get("P2N_FPS_G", "auto"), "ms": ms, "us_per_sample": 1e3 * ms / M,
                       "status": ops.fps_status("cuda")}))
 else:
-    for (B, N, M, gs) in [(16, 8192, 2048, ["auto", 2, 4]), (1, 8192, 2048, ["auto", 2, 4, 8]), (1, 40000, 10000, [2, 3, 4, 5, 8, 16]),
-                          (8, 40000, 2000, [2, 4, 8]), (1, 150000, 4000, [8, 16, 32]), (1, 1000000, 2000, [49, 64])]:
+    for (B, N, M, gs) in [(16, 8192, 2048, ["auto", 2]), (1, 8192, 2048, ["auto", 2, 4]), (1, 2048, 512, ["auto"]),
+                          (1, 40000, 10000, ["auto", 4, 5, 8, 10, 16, 32]),
+                          (8, 40000, 2000, ["auto", 4, 8, 16]), (1, 150000, 4000, ["auto", 16, 32, 64]), (1, 1000000, 2000, ["auto", 64])]:
         for g in gs:
             env = dict(os.environ)
             if g != "auto": env["P2N_FPS_G"] = str(g)
