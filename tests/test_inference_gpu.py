@@ -41,3 +41,32 @@ def test_predict_requires_eval_mode(ref_weights):
     m = Point2Net().cuda().train()
     with pytest.raises(RuntimeError):
         predict(m, np.zeros((10, 3)))
+
+
+def test_point_cloud_inference_class_file_to_file(ref_weights, tmp_path):
+    """The reference's class surface (inference.py:43-219) from checkpoint + YAML + PLY on disk to the
+    three result files, against predict() on the same arrays."""
+    import yaml
+    from pointcloudsegmentation_amd import io as p2n_io
+    from pointcloudsegmentation_amd.inference import PointCloudInference, predict
+    rng = np.random.default_rng(5)
+    n = 3000
+    pts = rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])
+    col = rng.integers(0, 256, (n, 3)) / 255.0
+    p2n_io.write_point_cloud_ply(tmp_path / "scene.ply", pts, col)
+    torch.save({"epoch": 1, "model_state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in ref_weights.items()}},
+               tmp_path / "ckpt.pth")
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump({"model": {"embedding_dim": 64}}))
+    inf = PointCloudInference(str(tmp_path / "ckpt.pth"), str(tmp_path / "cfg.yaml"), device="cuda")
+    assert not inf.model.training
+    res = inf.run(str(tmp_path / "scene.ply"), str(tmp_path / "out" / "scene_labeled.ply"), eps=0.1, min_samples=20)
+    rp, rc, _ = p2n_io.read_point_cloud_ply(tmp_path / "scene.ply")
+    want = predict(inf.model, rp, rc, eps=0.1, min_samples=20)
+    np.testing.assert_array_equal(res["instance_labels"], want["instance_labels"])
+    np.testing.assert_array_equal(np.load(tmp_path / "out" / "scene_labeled_labels.npy"), want["instance_labels"])
+    _, lc, _ = p2n_io.read_point_cloud_ply(tmp_path / "out" / "scene_labeled.ply")
+    np.testing.assert_array_equal(inf.labeler.colors_to_labels(lc), want["instance_labels"])
+    assert (tmp_path / "out" / "scene_labeled_original.ply").exists()
+    np.testing.assert_array_equal(inf.cluster_embeddings(res["embeddings"], 0.1, 20), want["instance_labels"])
+    with pytest.raises(RuntimeError):
+        PointCloudInference(str(tmp_path / "ckpt.pth"), str(tmp_path / "cfg.yaml"), device="cpu")
