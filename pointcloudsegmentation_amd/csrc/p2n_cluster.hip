@@ -24,7 +24,16 @@
 #include <type_traits>
 #include "p2n_common.h"
 
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// The Gram products run on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate) with every
+// value split into two bf16 parts, x = hi + lo + r, |r| <= 2^-18 |x|: three products per k-step
+// (hi.hi + hi.lo + lo.hi) leave out lo.lo and the r terms, at most 3 * 2^-18 * sum|a_k b_k| <=
+// 1.2e-5 for unit vectors -- the band `tau` around eps^2 that goes to the exact test is widened by
+// that much, so the decisions (and the labels) are unchanged while a 32 x 32 x 64 tile costs
+// 12 x 32 instead of 32 x 64 matrix-pipe cycles.  Xb is that image:
+//   Xb[tile][ks = k/16][part hi|lo][lane = 32*h + point%32][8 bf16]  = part(x[point][16 ks + 8h + 0..7])
+// (1 KiB per fragment again, G fragments per 32-point tile); the fp32 image Xp stays for the exact test.
+typedef __bf16 cl_bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 typedef __attribute__((address_space(3))) void cl_lds_void;
 typedef const __attribute__((address_space(1))) void cl_gbl_void;
 
@@ -67,7 +76,7 @@ __device__ __forceinline__ float cl_np_sumsq(const float *e, int n) {
 // thread per point.  out_rm (N,D) row-major and/or the fragment image Xp + fp32 squared norms.
 __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restrict__ emb, long N, long Npad, int D, int G,
                                                            float *__restrict__ out_rm, float *__restrict__ Xp,
-                                                           float *__restrict__ nrm) {
+                                                           float *__restrict__ nrm, float *__restrict__ Xb) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= Npad) return;
     if (i >= N) {   // pad rows: zero vectors that are never anybody's neighbour
@@ -75,6 +84,7 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
             for (int k = 0; k < G * 8; k += 4) {
                 const int g = k >> 3, h = (k >> 2) & 1;
                 *reinterpret_cast<f32x4 *>(Xp + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(Xb + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             nrm[i] = -__builtin_inff();
         }
@@ -96,6 +106,17 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
         if (Xp) {
             const int g = k >> 3, h = (k >> 2) & 1;
             *reinterpret_cast<f32x4 *>(Xp + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = v;
+            // split image: dims k..k+3 are elements 4*(k/4 % 2).. of lane half (k/8 % 2) of k-step k/16
+            const int ks = k >> 4, hb = (k >> 3) & 1, e0 = k & 4;
+            unsigned short *fh = reinterpret_cast<unsigned short *>(Xb + (((i >> 5) * G + 2 * ks) * 64 + hb * 32 + (i & 31)) * 4);
+            unsigned short *fl = fh + 512;   // the lo fragment follows the hi fragment (1 KiB = 512 halves)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __bf16 hi = (__bf16)v[j];
+                const __bf16 lo = (__bf16)(v[j] - (float)hi);
+                fh[e0 + j] = __builtin_bit_cast(unsigned short, hi);
+                fl[e0 + j] = __builtin_bit_cast(unsigned short, lo);
+            }
         }
     }
     if (Xp) nrm[i] = (float)(-0.5 * sq);   // nh = -|x|^2/2, the accumulator start value of the pair passes
@@ -146,6 +167,7 @@ __device__ __forceinline__ int cl_unite(int *parent, int i, int j) {
 // ------------------------------------------------------------------ the pair pass
 struct ClArgs {
     const float *Xp;
+    const float *Xb;        // split-bf16 fragment image (the MFMA operands)
     const float *nrm_row;   // nh = -|x|^2/2 of the wave-owned points (-inf on pad rows)
     const float *nrm_col;   // nh of the streamed points (-inf: pad; pass 2: also non-core)
     long Npad;
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int f = wave * 8 + q;
-                __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xp + (jb * 32 + f) * 256 + lane * 4),
+                __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xb + (jb * 32 + f) * 256 + lane * 4),
                                                  (cl_lds_void *)(dst + f * 256), 16, 0, 0);
             }
         }
@@ -241,9 +263,14 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
     if (pfetch) lds[pslot] = __int_as_float(CL_LD(A.parent + jb_now * JB + (wave - 2) * 64 + lane));
     int pnext = 0;
 
-    f32x4 a[G];
+    constexpr int KS = G / 2;             // k-steps of 16
+    constexpr int NSL = 3 * KS;           // MFMA slots per tile: hi.hi, hi.lo, lo.hi per k-step
+    cl_bf16x8 ah[KS], al[KS];
 #pragma unroll
-    for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4 *>(A.Xp + ((i0 >> 5) * G + g) * 256 + lane * 4);
+    for (int ks = 0; ks < KS; ++ks) {
+        ah[ks] = *reinterpret_cast<const cl_bf16x8 *>(A.Xb + ((i0 >> 5) * G + 2 * ks) * 256 + lane * 4);
+        al[ks] = *reinterpret_cast<const cl_bf16x8 *>(A.Xb + ((i0 >> 5) * G + 2 * ks + 1) * 256 + lane * 4);
+    }
     const float hh = -A.nrm_row[my] - 0.5f * A.eps2f;   // nrm_* hold -|x|^2/2 (-inf on pad rows: h = +inf, nothing reaches it)
     const float hm = hh - 0.5f * A.tau, hd = hh + 0.5f * A.tau;
     const bool mycore = MODE == 1 && A.core[my];
@@ -262,11 +289,12 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
             }
     };
     auto mfma_slot = [&](f32x16(&acc)[UT], const float *ubuf, int sl) __attribute__((always_inline)) {
-        const int g = sl >> 2, q = sl & 3;
+        const int ks = sl / 3, term = sl % 3;
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(ubuf + (ut * G + g) * 256 + lane * 4);   // CSE'd over q
-            acc[ut] = MFMA32(b[q], a[g][q], acc[ut]);   // rows = streamed points, columns = this wave's points
+            // rows = streamed points (hi fragment for the first two terms: CSE'd), columns = this wave's points
+            const cl_bf16x8 b = *reinterpret_cast<const cl_bf16x8 *>(ubuf + (ut * G + 2 * ks + (term == 2)) * 256 + lane * 4);
+            acc[ut] = MFMAB(b, term == 1 ? al[ks] : ah[ks], acc[ut]);
         }
     };
     auto fast_pair = [&](const f32x16(&acc)[UT], int e) __attribute__((always_inline)) {
@@ -340,7 +368,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
                 const long nxt = (cur + 1 == len) ? 0 : cur + 1;
                 const long nn = (nxt + 1 == len) ? 0 : nxt + 1;
                 const long jb_after = jbof(nn);
-                __syncthreads();   // block jb_cur has landed (vmcnt(0) + barrier); the other buffer is free
+                p2n_dma_barrier();   // block jb_cur has landed (explicit vmcnt(0) + barrier); the other buffer is free
                 if (MODE == 1) pi = CL_LD(A.parent + my);   // queued before the DMA: vmcnt completes in order
                 if (pfetch && t + 1 < len) pnext = CL_LD(A.parent + jb_nxt * JB + (wave - 2) * 64 + lane);
                 if (t + 1 < len) stage(jb_nxt, (int)((t + 1) & 1));
@@ -358,16 +386,16 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
         if (active && prev_active) {   // the steady state: one straight-line block, compares between the MFMAs
             init_acc(accn, blk, u);
 #pragma unroll
-            for (int sl = 0; sl < 4 * G; ++sl) {
+            for (int sl = 0; sl < NSL; ++sl) {
                 mfma_slot(accn, ubuf, sl);
 #pragma unroll
-                for (int e = sl * EL / (4 * G); e < (sl + 1) * EL / (4 * G); ++e) fast_pair(accp, e);
+                for (int e = sl * EL / NSL; e < (sl + 1) * EL / NSL; ++e) fast_pair(accp, e);
             }
         } else {
             if (active) {
                 init_acc(accn, blk, u);
 #pragma unroll
-                for (int sl = 0; sl < 4 * G; ++sl) mfma_slot(accn, ubuf, sl);
+                for (int sl = 0; sl < NSL; ++sl) mfma_slot(accn, ubuf, sl);
             }
             if (prev_active) {
 #pragma unroll
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(256) void cl_label_kernel(const int *__restrict__ p
 
 // ------------------------------------------------------------------ host side
 struct ClWs {
-    float *Xp, *nrm, *nrm_core;
+    float *Xp, *Xb, *nrm, *nrm_core;
     int *cnt, *parent, *nbr_cnt, *rank, *blk_has_core, *nbr;
     unsigned char *core;
     unsigned long long *stats;
@@ -569,6 +597,7 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         return p;
     };
     w.Xp = (float *)take(sizeof(float) * (size_t)Npad * G * 8);
+    w.Xb = (float *)take(sizeof(float) * (size_t)Npad * G * 8);   // hi + lo bf16 per value: the same size
     w.nrm = (float *)take(sizeof(float) * (Npad + 64));        // + 64: the 64-dword block prefetch may overrun
     w.nrm_core = (float *)take(sizeof(float) * (Npad + 64));
     w.cnt = (int *)take(sizeof(int) * Npad);
@@ -618,7 +647,7 @@ extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, v
     P2N_REQUIRE(emb && out, "p2n_normalize_rows: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(cl_normalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, N, D, (D + 7) / 8,
-                       out, (float *)nullptr, (float *)nullptr);
+                       out, (float *)nullptr, (float *)nullptr, (float *)nullptr);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
@@ -660,7 +689,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     }
     const unsigned nb256 = (unsigned)((Npad + 255) / 256);
     int ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
-    hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm);
+    hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm, w.Xb);
     const int nb128 = (int)(Npad / 128);
     hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (8 * G + 128), stream, w.Xp, w.nrm, G, w.centre,
                        w.radius);
@@ -672,10 +701,12 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     p2n_prof_end(ps, stream);
 
     ClArgs a;
-    a.Xp = w.Xp; a.nrm_row = w.nrm; a.nrm_col = w.nrm; a.Npad = Npad;
+    a.Xp = w.Xp; a.Xb = w.Xb; a.nrm_row = w.nrm; a.nrm_col = w.nrm; a.Npad = Npad;
     a.eps2 = eps * eps;
     a.eps2f = (float)a.eps2;
-    a.tau = 2.5e-5f * (float)(G / 8);   // > 2 * (8G) * 2^-24 (dot of unit vectors) + norm and threshold roundings
+    // > 2 * (8G) * 2^-24 (fp32 accumulation of a dot of unit vectors) + norm and threshold roundings,
+    // + 2 * 1.2e-5 for the products the bf16 split leaves out (tau is on the d2 scale: twice the dot's)
+    a.tau = 2.5e-5f * (float)(G / 8) + 2.5e-5f;
     a.cnt = w.cnt; a.parent = w.parent; a.core = w.core; a.colblk_has_core = w.blk_has_core;
     a.nbr_cnt = w.nbr_cnt; a.nbr = w.nbr; a.cap = cap; a.stats = w.stats;
     const long nrowblk = Npad / CL_ROWBLK;

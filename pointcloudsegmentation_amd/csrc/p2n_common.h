@@ -71,6 +71,18 @@ static inline P2nLayout p2n_make_layout(int F, int E) {
     return L;
 }
 
+// Barrier that publishes LDS-DMA data (global_load ... lds).  The compiler does not always count an
+// LDS-DMA as something a workgroup barrier has to wait for (seen in the clustering pair kernel: only
+// s_waitcnt lgkmcnt(0) in front of s_barrier), so the wait is spelled out: every wave drains its own
+// vector-memory queue (vmcnt(0): the DMA has written LDS) before it signals the barrier.
+// s_waitcnt encoding on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14].
+#ifdef __HIPCC__
+__device__ __forceinline__ void p2n_dma_barrier() {
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8) | (0 << 14));   // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
+}
+#endif
+
 // ---- optional per-kernel timing (p2n_api.hip) ----
 #define P2N_K_ENCODER 0
 #define P2N_K_MID 1

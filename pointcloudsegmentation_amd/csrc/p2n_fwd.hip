@@ -124,11 +124,11 @@ __device__ __forceinline__ void stage_chunk(const float *__restrict__ stream, fl
 }
 
 // Entering fragment f of the stream: at a chunk boundary wait for the chunk (vmcnt(0) +
-// barrier inside __syncthreads), which also proves every wave left the other buffer,
+// barrier, p2n_dma_barrier), which also proves every wave left the other buffer,
 // then start the DMA of the next chunk into that other buffer.
 __device__ __forceinline__ void chunk_gate(int f, const float *__restrict__ stream, float *wbuf, int wave, int lane) {
     if (f % P2N_CHUNK == 0) {
-        __syncthreads();
+        p2n_dma_barrier();
         stage_chunk(stream, wbuf, f / P2N_CHUNK + 1, wave, lane);
     }
 }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
                 }
         }
     }
-    __syncthreads();
+    p2n_dma_barrier();   // also drains the spare chunk's DMA before the workgroup's LDS is released
     A.partial[(long)blockIdx.x * 256 + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
 }
 
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
 #pragma unroll 1
     for (int c8 = 0; c8 < nch8; ++c8) {
         const int c = 12 + c8;
-        __syncthreads();
+        p2n_dma_barrier();
         stage_chunk(stream, wbuf, c + 1, wave, lane);
         const float *wb = wbuf + (c & 1) * CHUNK_FLOATS + lane * 4;
 #pragma unroll
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
         }
     }
     // drain the spare chunk's DMA before the workgroup's LDS is released
-    __syncthreads();
+    p2n_dma_barrier();
 }
 
 // ------------------------------------------------------------------ C ABI

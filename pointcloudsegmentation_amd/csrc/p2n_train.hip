@@ -153,12 +153,12 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
-    __syncthreads();   // tab visible (and chunk 0 landed)
+    p2n_dma_barrier();   // tab visible (and chunk 0 landed)
     f32x16 cur = tl_transform<MODE>(A, 0, valid, h, tab, KP, r0, r1);
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         if (kt % KPC == 0) {
-            if (kt) __syncthreads();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
+            if (kt) p2n_dma_barrier();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
             tl_stage(A.wimg, wbuf, kt / KPC + 1, wave, lane);
         }
         if (kt + 1 < KT) tl_fetch<MODE>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
             }
         }
     }
-    __syncthreads();   // the spare chunk's DMA must land before the workgroup's LDS is released
+    p2n_dma_barrier();   // the spare chunk's DMA must land before the workgroup's LDS is released
 }
 
 // ---------------------------------------------------------------- wgrad: dW = dz . a^T over points
