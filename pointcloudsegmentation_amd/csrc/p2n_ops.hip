@@ -355,52 +355,71 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
 }
 
 // =========================================================================== ball query
-// One thread per query, the cloud streamed through LDS as SoA tiles (coalesced
-// loads, broadcast ds_read_b128 of four x / y / z at a time).
-#define BQ_THREADS 256
-#define BQ_TILE 2048
+// One WAVE serves two queries (the kNN kernel's shape): the cloud streams through LDS as SoA tiles,
+// the 64 lanes test 64 consecutive points against both queries with packed fp32 arithmetic, a ballot
+// gives the hits in index order and a lane's rank among them (popcount of the lower lanes) is its
+// output slot.  A query is finished as soon as it has nsample hits (wave-uniform, no divergence), a
+// workgroup as soon as all its queries are.  The first version ran one THREAD per query: 2 waves per
+// CU at the set-abstraction shapes and a scattered store per hit.
+#define BQ_WAVES 8
+#define BQ_TILE 4096   // points per LDS tile (48 KiB)
 
-__global__ __launch_bounds__(BQ_THREADS) void p2n_ball_query_kernel(const float *__restrict__ xyz,
-                                                                   const float *__restrict__ new_xyz, int N, int M,
-                                                                   float r2, int ns, int32_t *__restrict__ idx) {
+__global__ __launch_bounds__(BQ_WAVES * 64) void p2n_ball_query_kernel(const float *__restrict__ xyz,
+                                                                      const float *__restrict__ new_xyz, int N, int M,
+                                                                      float r2, int ns, int32_t *__restrict__ idx) {
     __shared__ __attribute__((aligned(16))) float sx[BQ_TILE], sy[BQ_TILE], sz[BQ_TILE];
-    const int b = blockIdx.y, m = blockIdx.x * BQ_THREADS + threadIdx.x;
-    const bool active = m < M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const long m0 = 2 * ((long)blockIdx.x * BQ_WAVES + wave);
     const float *P = xyz + (long)b * N * 3;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (active) {
-        const float *q = new_xyz + ((long)b * M + m) * 3;
-        qx = q[0]; qy = q[1]; qz = q[2];
+    f32x2 qx = {0.f, 0.f}, qy = {0.f, 0.f}, qz = {0.f, 0.f};
+    int cnt[2], first[2] = {0, 0};
+    int32_t *o[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const bool act = m0 + q < M;
+        const long m = act ? m0 + q : 0;
+        const float *c = new_xyz + ((long)b * M + m) * 3;
+        qx[q] = c[0]; qy[q] = c[1]; qz[q] = c[2];
+        o[q] = idx + ((long)b * M + m) * ns;
+        cnt[q] = act ? 0 : ns;   // a query past the end counts as finished and writes nothing
     }
-    int32_t *o = idx + ((long)b * M + (active ? m : 0)) * ns;
-    int cnt = active ? 0 : ns, first = 0;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));   // lanes lower than this one
     for (int t0 = 0; t0 < N; t0 += BQ_TILE) {
         const int tn = min(BQ_TILE, N - t0);
         __syncthreads();
-        for (int i = threadIdx.x; i < tn; i += BQ_THREADS) {
+        for (int i = threadIdx.x; i < tn; i += BQ_WAVES * 64) {
             sx[i] = P[(long)(t0 + i) * 3 + 0];
             sy[i] = P[(long)(t0 + i) * 3 + 1];
             sz[i] = P[(long)(t0 + i) * 3 + 2];
         }
         __syncthreads();
-        if (__syncthreads_and(cnt >= ns)) break;
-        if (cnt < ns) {
-            for (int i = 0; i < tn && cnt < ns; i += 4) {
-                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(&sx[i]);
-                const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&sy[i]);
-                const f32x4 z4 = *reinterpret_cast<const f32x4 *>(&sz[i]);
+        if (__syncthreads_and(cnt[0] >= ns && cnt[1] >= ns)) break;
+        for (int i0 = 0; i0 < tn && (cnt[0] < ns || cnt[1] < ns); i0 += 64) {
+            const int i = i0 + lane;
+            const bool in = i < tn;
+            const float x = in ? sx[i] : 0.f, y = in ? sy[i] : 0.f, z = in ? sz[i] : 0.f;
+            // ((dx*dx + dy*dy) + dz*dz) with the candidate first, as sqdist3(point, query): every operation
+            // rounded on its own (-ffp-contract=off), both queries at once
+            const f32x2 dx = f32x2{x, x} - qx, dy = f32x2{y, y} - qy, dz = f32x2{z, z} - qz;
+            const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (i + j < tn && cnt < ns && sqdist3(x4[j], y4[j], z4[j], qx, qy, qz) < r2) {
-                        if (cnt == 0) first = t0 + i + j;
-                        o[cnt++] = t0 + i + j;
-                    }
-                }
+            for (int q = 0; q < 2; ++q) {
+                if (cnt[q] >= ns) continue;   // wave-uniform
+                const bool hit = in && dd[q] < r2;
+                const unsigned long long mask = __ballot(hit);
+                if (!mask) continue;
+                if (cnt[q] == 0) first[q] = t0 + i0 + __builtin_ctzll(mask);
+                const int slot = cnt[q] + __builtin_popcountll(mask & below);
+                if (hit && slot < ns) o[q][slot] = t0 + i;
+                cnt[q] += __builtin_popcountll(mask);
             }
         }
     }
-    if (active)
-        for (int s = cnt; s < ns; ++s) o[s] = first;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (m0 + q < M)
+            for (int s = cnt[q] + lane; s < ns; s += 64) o[q][s] = first[q];   // pad with the first hit (0 if none)
 }
 
 extern "C" int p2n_ball_query(const float *xyz, const float *new_xyz, int B, int N, int M, float radius, int nsample,
@@ -410,9 +429,10 @@ extern "C" int p2n_ball_query(const float *xyz, const float *new_xyz, int B, int
     if (B == 0 || M == 0) return P2N_OK;
     P2N_REQUIRE(xyz && new_xyz && idx, "p2n_ball_query: null pointer");
     P2N_REQUIRE(B <= 65535, "p2n_ball_query: B > 65535");
+    const long blocks = ((long)M + 2 * BQ_WAVES - 1) / (2 * BQ_WAVES);
     const int ps = p2n_prof_begin(P2N_K_BALL, (hipStream_t)stream);
-    hipLaunchKernelGGL(p2n_ball_query_kernel, dim3((M + BQ_THREADS - 1) / BQ_THREADS, B), dim3(BQ_THREADS), 0,
-                       (hipStream_t)stream, xyz, new_xyz, N, M, radius * radius, nsample, idx);
+    hipLaunchKernelGGL(p2n_ball_query_kernel, dim3((unsigned)blocks, B), dim3(BQ_WAVES * 64), 0, (hipStream_t)stream, xyz,
+                       new_xyz, N, M, radius * radius, nsample, idx);
     p2n_prof_end(ps, (hipStream_t)stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
