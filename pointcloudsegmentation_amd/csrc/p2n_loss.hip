@@ -225,9 +225,10 @@ __global__ __launch_bounds__(256) void p2n_pull_b_kernel(const float *__restrict
     }
 }
 
+// ---- smoothness, generic form (any E): one neighbour at a time ----
 // smoothness forward: part[block] = sum over the block's points of sum_{j=1..k} |en[nbr_j] - en[p]|
 // (idx has k+1 columns; column 0 is dropped as the reference does, losses.py:479)
-__global__ __launch_bounds__(256) void p2n_smooth_fwd_kernel(const float *__restrict__ en, const int *__restrict__ idx,
+__global__ __launch_bounds__(256) void p2n_smooth_fwd_generic_kernel(const float *__restrict__ en, const int *__restrict__ idx,
                                                             long P, int N, int E, int k1, float *__restrict__ part) {
     __shared__ float sh[4];
     const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void p2n_smooth_fwd_kernel(const float *__rest
 
 // smoothness backward w.r.t. en: den[q] += w*(en_q - en_p)/d (atomics: q is a neighbour of many
 // points), den[p] -= the sum of the same terms (accumulated in registers, one atomic per element)
-__global__ __launch_bounds__(256) void p2n_smooth_bwd_kernel(const float *__restrict__ en, const int *__restrict__ idx,
+__global__ __launch_bounds__(256) void p2n_smooth_bwd_generic_kernel(const float *__restrict__ en, const int *__restrict__ idx,
                                                             long P, int N, int E, int k1, float w,
                                                             float *__restrict__ den) {
     const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -284,6 +285,115 @@ __global__ __launch_bounds__(256) void p2n_smooth_bwd_kernel(const float *__rest
     for (int c = lane; c < E; c += 64, ++c4) atomicAdd(&den[p * E + c], self[c4]);
 }
 
+// ---- smoothness, row-parallel form (E <= 256) ------------------------------------------------
+// A wave owns one point; its four 16-lane rows each take one neighbour at a time, a lane holds
+// 4 * V channels of that neighbour's row.  The k neighbour indices are
+// fetched with one load, and the row loads of SM_U neighbour groups (4 * SM_U neighbours) are all in
+// flight before the first distance is reduced: the first version walked the neighbours one by one,
+// index load -> row load -> 64-lane shuffle reduction, each step waiting for the one before.
+#define SM_U 5   // neighbour groups in flight (20 neighbours: the reference's k)
+
+__device__ __forceinline__ float row16_sum(float v) {   // sum over each 16-lane row, in every lane of the row
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+template <int V, bool BWD>
+__global__ __launch_bounds__(256) void p2n_smooth_vec_kernel(const float *__restrict__ en, const int *__restrict__ idx,
+                                                            long P, int N, int E, int k1, float w,
+                                                            float *__restrict__ part, float *__restrict__ den) {
+    __shared__ float sh[4];
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+    const bool live = p < P;
+    const long pp = live ? p : 0;
+    const long base = (pp / N) * (long)N;
+    // all neighbour indices of the point with one load (k1 <= 64): lane j holds column j
+    const int myidx = (live && lane < k1) ? idx[pp * k1 + lane] : 0;
+    // element (v, e) of a lane is channel 64 v + 16 e + l: every load / atomic instruction touches 16
+    // consecutive floats (one 64-byte segment) per row
+    float ep[V][4], self[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 64 * v + 16 * e + l;
+            ep[v][e] = c < E ? en[pp * E + c] : 0.f;
+            self[v][e] = 0.f;
+        }
+    float acc = 0.f;
+    const int T = (k1 - 1 + 3) / 4;   // neighbour groups of four
+    for (int t0 = 0; t0 < T; t0 += SM_U) {
+        long q[SM_U];
+        bool ok[SM_U];
+        float eq[SM_U][V][4];
+#pragma unroll
+        for (int u = 0; u < SM_U; ++u) {
+            const int j = 1 + 4 * (t0 + u) + g;   // column 0 is the point itself (reference losses.py:479)
+            ok[u] = live && j < k1;
+            q[u] = base + __shfl(myidx, ok[u] ? j : 0);
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 64 * v + 16 * e + l;
+                    eq[u][v][e] = (ok[u] && c < E) ? en[q[u] * E + c] : ep[v][e];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < SM_U; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    eq[u][v][e] -= ep[v][e];
+                    s = fmaf(eq[u][v][e], eq[u][v][e], s);
+                }
+            s = row16_sum(s);
+            const float d = sqrtf(s);
+            if (!BWD) {
+                acc += (ok[u] && l == 0) ? d : 0.f;
+            } else if (ok[u] && d > 0.f) {
+                const float r = w / d;
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 64 * v + 16 * e + l;
+                        if (c < E) {
+                            const float gq = eq[u][v][e] * r;
+                            atomicAdd(&den[q[u] * E + c], gq);
+                            self[v][e] -= gq;
+                        }
+                    }
+            }
+        }
+    }
+    if (!BWD) {
+        acc = block_sum(acc, sh);
+        if (threadIdx.x == 0) part[blockIdx.x] = acc;
+    } else {
+        // the four rows' shares of den[p]: add them up inside the wave, one atomic per element
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = self[v][e];
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                const int c = 64 * v + 16 * e + l;
+                if (live && g == 0 && c < E) atomicAdd(&den[p * E + c], t);
+            }
+    }
+}
+
+static void smooth_launch(bool bwd, const float *en, const int *idx, long P, int N, int E, int k1, float w, float *part,
+                          float *den, unsigned blocks, hipStream_t s);
+
 // out[0..2] = {pull, push, smooth}: deterministic final sums
 __global__ __launch_bounds__(256) void p2n_loss_finalize_kernel(const float *__restrict__ pull_b,
                                                                const float *__restrict__ push_b, int B,
@@ -297,6 +407,27 @@ __global__ __launch_bounds__(256) void p2n_loss_finalize_kernel(const float *__r
     b = block_sum(b, sh);
     c = block_sum(c, sh);
     if (threadIdx.x == 0) { out[0] = a / (float)B; out[1] = b / (float)B; out[2] = c * smooth_scale; }
+}
+
+static void smooth_launch(bool bwd, const float *en, const int *idx, long P, int N, int E, int k1, float w, float *part,
+                          float *den, unsigned blocks, hipStream_t s) {
+    const bool vec = E <= 256 && k1 <= 64;
+    if (!vec) {
+        if (bwd) hipLaunchKernelGGL(p2n_smooth_bwd_generic_kernel, dim3(blocks), dim3(256), 0, s, en, idx, P, N, E, k1, w, den);
+        else hipLaunchKernelGGL(p2n_smooth_fwd_generic_kernel, dim3(blocks), dim3(256), 0, s, en, idx, P, N, E, k1, part);
+        return;
+    }
+    const int V = (E + 63) / 64;
+#define SM_GO(VV)                                                                                                         \
+    do {                                                                                                                  \
+        if (bwd) hipLaunchKernelGGL((p2n_smooth_vec_kernel<VV, true>), dim3(blocks), dim3(256), 0, s, en, idx, P, N, E, k1, w, part, den); \
+        else hipLaunchKernelGGL((p2n_smooth_vec_kernel<VV, false>), dim3(blocks), dim3(256), 0, s, en, idx, P, N, E, k1, w, part, den);   \
+    } while (0)
+    if (V == 1) SM_GO(1);
+    else if (V == 2) SM_GO(2);
+    else if (V == 3) SM_GO(3);
+    else SM_GO(4);
+#undef SM_GO
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -377,7 +508,7 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     // smoothness: brute-force kNN of every point within its cloud (k+1 incl. the point itself)
     int rc = p2n_knn(points, points, B, N, N, k1, w.idx, nullptr, stream_);
     if (rc) return rc;
-    hipLaunchKernelGGL(p2n_smooth_fwd_kernel, dim3(pb), dim3(256), 0, s, w.en, w.idx, P, N, E, k1, w.spart);
+    smooth_launch(false, w.en, w.idx, P, N, E, k1, 0.f, w.spart, nullptr, (unsigned)pb, s);
     P2N_CHECK_HIP(hipGetLastError());
     const float smooth_scale = 1.0f / ((float)N * (float)k) / (float)B;
     hipLaunchKernelGGL(p2n_loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.pull_b, w.push_b, B, w.spart, (long)pb,
@@ -392,7 +523,7 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, demb_push, w.en, w.rn, P, E, demb_push);
     P2N_CHECK_HIP(hipGetLastError());
     P2N_CHECK_HIP(hipMemsetAsync(w.den, 0, sizeof(float) * P * E, s));
-    hipLaunchKernelGGL(p2n_smooth_bwd_kernel, dim3(pb), dim3(256), 0, s, w.en, w.idx, P, N, E, k1, smooth_scale, w.den);
+    smooth_launch(true, w.en, w.idx, P, N, E, k1, smooth_scale, nullptr, w.den, (unsigned)pb, s);
     P2N_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, w.den, w.en, w.rn, P, E, demb_smooth);
     P2N_CHECK_HIP(hipGetLastError());
