@@ -71,6 +71,100 @@ __global__ __launch_bounds__(256) void p2n_seg_sum_kernel(const float *__restric
     for (int c = lane; c < E; c += 64) atomicAdd(&sums[(long)i * E + c], en[p * E + c]);
 }
 
+// Workgroup-private form of the two per-instance accumulations (seg_sum above, pull pass A below):
+// a workgroup walks SEG_CHUNK consecutive points of ONE cloud and adds into an LDS copy of that
+// cloud's instance rows (ids of a cloud are contiguous, cstart), then flushes the rows it touched
+// with one global atomic per element.  The direct form sends 64 global atomics per point to a few
+// dozen rows: 262,144 points hammer ~1,000 addresses-rows and the memory-side atomic units serialise.
+// MODE 0: sums[i] += en[p].  MODE 1: pullsum[i] += max(|en[p]-mu[i]| - delta_v, 0), G[i] += unit vector.
+#define SEG_CHUNK 512
+#define SEG_THREADS 1024   // 16 waves x 4 points per step: a wave walks 32 points (each step is a chain of dependent loads)
+#define SEG_MAX_LDS (60 * 1024)
+template <int MODE>
+__global__ __launch_bounds__(SEG_THREADS) void p2n_seg_lds_kernel(const float *__restrict__ en, const int *__restrict__ inst,
+                                                         const int *__restrict__ bg, const int *__restrict__ cstart,
+                                                         const float *__restrict__ mu, int N, int E, float delta_v,
+                                                         int want_grad, float *__restrict__ rows_out,
+                                                         float *__restrict__ pullsum, int cap) {
+    extern __shared__ float lacc[];   // [Tb][E] (+ [Tb] hinge sums for MODE 1)
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = cstart[b], Tb = cstart[b + 1] - c0;
+    // a cloud with more instance rows than the LDS copy holds (cap) adds straight into global memory
+    const bool priv = Tb <= cap;
+    float *gacc = rows_out + (long)c0 * E;   // the same rows in global memory
+    float *lhs = lacc + (long)Tb * E;
+    // separate LDS / global atomics (one generic pointer would turn both into flat atomics)
+    auto add_row = [&](int off, float val) __attribute__((always_inline)) {
+        if (priv) atomicAdd(&lacc[off], val);
+        else atomicAdd(&gacc[off], val);
+    };
+    if (priv) {
+        const int nacc = Tb * E + (MODE == 1 ? Tb : 0);
+        for (int i = threadIdx.x; i < nacc; i += SEG_THREADS) lacc[i] = 0.f;
+    }
+    __syncthreads();
+    const int n0 = blockIdx.x * SEG_CHUNK;
+    const int n1 = min(N, n0 + SEG_CHUNK);
+    for (int nb = n0 + wave * 4; nb < n1; nb += SEG_THREADS / 16) {   // four points per wave step, loads first
+        int li[4];
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = nb + u;
+            li[u] = -1;
+            if (n < n1) {
+                const int i = inst[(long)b * N + n];
+                if (!bg[i]) li[u] = i - c0;
+            }
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int c = lane + 64 * c4;
+                v[u][c4] = (n < n1 && c < E) ? en[((long)b * N + n) * E + c] : 0.f;   // not behind the inst -> bg chain
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (li[u] < 0) continue;   // wave-uniform
+            if (MODE == 0) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int c = lane + 64 * c4;
+                    if (c < E) add_row(li[u] * E + c, v[u][c4]);
+                }
+            } else {
+                float d[4], s = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int c = lane + 64 * c4;
+                    d[c4] = c < E ? v[u][c4] - mu[(long)(c0 + li[u]) * E + c] : 0.f;
+                    s = fmaf(d[c4], d[c4], s);
+                }
+                s = wave_sum(s);
+                const float dist = sqrtf(s);
+                const float hv = dist - delta_v;
+                if (hv > 0.f) {
+                    if (lane == 0) { if (priv) atomicAdd(&lhs[li[u]], hv); else atomicAdd(&pullsum[c0 + li[u]], hv); }
+                    if (want_grad && dist > 0.f) {
+                        const float r = 1.0f / dist;
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const int c = lane + 64 * c4;
+                            if (c < E) add_row(li[u] * E + c, d[c4] * r);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!priv) return;
+    for (int i = threadIdx.x; i < Tb * E; i += SEG_THREADS)
+        if (lacc[i] != 0.f) atomicAdd(&rows_out[(long)c0 * E + i], lacc[i]);
+    if (MODE == 1)
+        for (int i = threadIdx.x; i < Tb; i += SEG_THREADS)
+            if (lhs[i] != 0.f) atomicAdd(&pullsum[c0 + i], lhs[i]);
+}
+
 // One workgroup per cloud: means, normalised means, push loss and its gradient w.r.t. the means.
 //   mu[i] = sums[i]/cnt[i]; nmu = mu/max(|mu|,eps)
 //   push_b = sum_{i<j} max(2*delta_d - |nmu_i - nmu_j|, 0) / (pairs + 1e-6)      (losses.py:431-441)
@@ -391,6 +485,165 @@ __global__ __launch_bounds__(256) void p2n_smooth_vec_kernel(const float *__rest
     }
 }
 
+// ---- smoothness backward without float atomics ---------------------------------------------------
+// d/d en[q] of sum_p sum_{x in N(p)} |en[x] - en[p]| collects one unit vector per edge that touches q:
+//   den[q] = w * sum over x in N(q) and over p with q in N(p) of (en[q] - en[x or p]) / |en[q] - en[..]|.
+// The scatter form above sends 64 float atomics per edge (335 M at B=32 x 8192 x 20: the memory-side
+// atomic rate bounds it at ~1.1 ms).  Here the reverse neighbour lists are built first (in-degree
+// count, exclusive scan, fill: integer atomics, one per edge) and every point then PULLS both of its
+// lists, 16 lanes per row, accumulating in registers and storing den[q] once -- no memset, no float atomic.
+__global__ __launch_bounds__(256) void p2n_rev_count_kernel(const int *__restrict__ idx, long P, int N, int k1,
+                                                           int *__restrict__ deg) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long p = e / k1;
+    const int j = (int)(e % k1);
+    if (p >= P || j == 0) return;
+    atomicAdd(&deg[(p / N) * (long)N + idx[e]], 1);
+}
+
+// exclusive scan of deg[0..P) -> off[0..P], three launches: per-block scan of 1024 elements, scan of the
+// block totals by one workgroup, offset add
+__global__ __launch_bounds__(256) void p2n_scan_block_kernel(const int *__restrict__ in, long n, int *__restrict__ out,
+                                                            int *__restrict__ totals) {
+    __shared__ int sh[256];
+    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = i0 + q < n ? in[i0 + q] : 0; s += v[q]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - s;   // exclusive prefix of this thread inside the block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { if (i0 + q < n) out[i0 + q] = run; run += v[q]; }
+    if (threadIdx.x == 255) totals[blockIdx.x] = sh[255];
+}
+
+__global__ __launch_bounds__(256) void p2n_scan_totals_kernel(int *__restrict__ totals, long nb, int *__restrict__ grand) {
+    __shared__ int sh[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long b0 = 0; b0 < nb; b0 += 256) {
+        const long i = b0 + threadIdx.x;
+        const int v = i < nb ? totals[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) totals[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *grand = carry;
+}
+
+__global__ __launch_bounds__(256) void p2n_scan_add_kernel(int *__restrict__ out, long n, const int *__restrict__ totals) {
+    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int t = totals[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i0 + q < n) out[i0 + q] += t;
+}
+
+// rev[off[q] + slot] = p for every edge p -> q; deg[] counts down to zero (the slot order is arbitrary)
+__global__ __launch_bounds__(256) void p2n_rev_fill_kernel(const int *__restrict__ idx, long P, int N, int k1,
+                                                          const int *__restrict__ off, int *__restrict__ deg,
+                                                          int *__restrict__ rev) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long p = e / k1;
+    const int j = (int)(e % k1);
+    if (p >= P || j == 0) return;
+    const long q = (p / N) * (long)N + idx[e];
+    const int slot = atomicSub(&deg[q], 1) - 1;
+    rev[off[q] + slot] = (int)(p % N);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__restrict__ en, const int *__restrict__ idx,
+                                                             const int *__restrict__ off, const int *__restrict__ rev,
+                                                             long P, int N, int E, int k1, float w,
+                                                             float *__restrict__ den) {
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+    if (p >= P) return;   // whole wave
+    const long base = (p / N) * (long)N;
+    const int myidx = lane < k1 ? idx[p * k1 + lane] : 0;
+    const int r0 = off[p], nrev = off[p + 1] - r0;
+    const int k = k1 - 1, total = k + nrev;
+    float ep[V][4], acc[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 64 * v + 16 * e + l;
+            ep[v][e] = c < E ? en[p * E + c] : 0.f;
+            acc[v][e] = 0.f;
+        }
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        // lane t holds list position t0 + t: own neighbours first, then the points that list p
+        const int pos = t0 + lane;
+        int cand = __shfl(myidx, pos < k ? pos + 1 : 0);
+        if (pos >= k && pos < total) cand = rev[r0 + pos - k];
+        const int chunk = min(64, total - t0);
+        for (int u0 = 0; u0 < chunk; u0 += 4 * SM_U) {
+            bool ok[SM_U];
+            float eq[SM_U][V][4];
+#pragma unroll
+            for (int u = 0; u < SM_U; ++u) {
+                const int t = u0 + 4 * u + g;
+                ok[u] = t < chunk;
+                const long q = base + __shfl(cand, ok[u] ? t : 0);
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 64 * v + 16 * e + l;
+                        eq[u][v][e] = (ok[u] && c < E) ? en[q * E + c] : ep[v][e];
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < SM_U; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        eq[u][v][e] = ep[v][e] - eq[u][v][e];
+                        s = fmaf(eq[u][v][e], eq[u][v][e], s);
+                    }
+                s = row16_sum(s);
+                const float d = sqrtf(s);
+                const float r = (ok[u] && d > 0.f) ? w / d : 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[v][e] = fmaf(eq[u][v][e], r, acc[v][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = acc[v][e];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            const int c = 64 * v + 16 * e + l;
+            if (g == 0 && c < E) den[p * E + c] = t;
+        }
+}
+
 static void smooth_launch(bool bwd, const float *en, const int *idx, long P, int N, int E, int k1, float w, float *part,
                           float *den, unsigned blocks, hipStream_t s);
 
@@ -434,7 +687,7 @@ static void smooth_launch(bool bwd, const float *en, const int *idx, long P, int
 namespace {
 struct LossWs {
     float *en, *rn, *sums, *mu, *nmu, *dmu, *G, *pullsum, *pull_b, *push_b, *coef, *spart, *den;
-    int *idx;
+    int *idx, *deg, *off, *rev, *totals;
     size_t total;
 };
 size_t loss_carve(LossWs &w, char *base, long P, int E, int T, int B, int k1) {
@@ -454,6 +707,10 @@ size_t loss_carve(LossWs &w, char *base, long P, int E, int T, int B, int k1) {
     w.spart = (float *)take(sizeof(float) * ((P + 3) / 4));
     w.den = (float *)take(sizeof(float) * P * E);
     w.idx = (int *)take(sizeof(int) * P * k1);
+    w.deg = (int *)take(sizeof(int) * (P + 4));
+    w.off = (int *)take(sizeof(int) * (P + 4));
+    w.rev = (int *)take(sizeof(int) * P * k1);
+    w.totals = (int *)take(sizeof(int) * ((P + 1023) / 1024 + 4));
     return off;
 }
 }  // namespace
@@ -494,13 +751,34 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     P2N_CHECK_HIP(hipGetLastError());
     // sums, G and pullsum are adjacent in the carve: zero them with one memset
     P2N_CHECK_HIP(hipMemsetAsync(w.sums, 0, (size_t)((char *)w.mu - (char *)w.sums), s));
-    hipLaunchKernelGGL(p2n_seg_sum_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, P, E, w.sums);
+    // workgroup-private accumulation: LDS holds up to seg_cap instance rows of one cloud (a cloud with
+    // more falls back to global atomics inside the kernel); E <= 256: four channels per lane
+    const int seg_cap = (int)(SEG_MAX_LDS / ((E + 1) * sizeof(float)));
+    const size_t seg_lds = (size_t)seg_cap * (E + 1) * sizeof(float);
+    const bool seg_private = E <= 256 && B <= 65535 && seg_cap >= 1;
+    const dim3 seg_grid((N + SEG_CHUNK - 1) / SEG_CHUNK, B);
+    if (seg_private) {
+        if (seg_lds > 48 * 1024) {
+            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_seg_lds_kernel<0>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));
+            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_seg_lds_kernel<1>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));
+        }
+        hipLaunchKernelGGL(p2n_seg_lds_kernel<0>, seg_grid, dim3(SEG_THREADS), seg_lds, s, w.en, inst, bg, cstart, (const float *)nullptr,
+                           N, E, 0.f, 0, w.sums, (float *)nullptr, seg_cap);
+    } else {
+        hipLaunchKernelGGL(p2n_seg_sum_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, P, E, w.sums);
+    }
     P2N_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(p2n_disc_cloud_kernel, dim3(B), dim3(256), 0, s, w.sums, cnt, bg, cstart, E, B, delta_d, w.mu, w.nmu,
                        w.dmu, w.push_b, want ? 1 : 0);
     P2N_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(p2n_pull_a_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, w.mu, P, E, delta_v, w.pullsum, w.G,
-                       want ? 1 : 0);
+    if (seg_private)
+        hipLaunchKernelGGL(p2n_seg_lds_kernel<1>, seg_grid, dim3(SEG_THREADS), seg_lds, s, w.en, inst, bg, cstart, w.mu, N, E, delta_v,
+                           want ? 1 : 0, w.G, w.pullsum, seg_cap);
+    else
+        hipLaunchKernelGGL(p2n_pull_a_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, w.mu, P, E, delta_v, w.pullsum, w.G,
+                           want ? 1 : 0);
     P2N_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(p2n_pull_cloud_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.pullsum, cnt, bg, cstart, B, w.pull_b,
                        w.coef);
@@ -522,8 +800,25 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, demb_pull, w.en, w.rn, P, E, demb_pull);
     hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, demb_push, w.en, w.rn, P, E, demb_push);
     P2N_CHECK_HIP(hipGetLastError());
-    P2N_CHECK_HIP(hipMemsetAsync(w.den, 0, sizeof(float) * P * E, s));
-    smooth_launch(true, w.en, w.idx, P, N, E, k1, smooth_scale, nullptr, w.den, (unsigned)pb, s);
+    if (E <= 256 && k1 <= 64 && P * (long)k1 < 0x7fffffffL) {
+        // reverse neighbour lists, then a pull per point (no float atomics)
+        const long ne = P * (long)k1, nb = (P + 1 + 1023) / 1024;
+        P2N_CHECK_HIP(hipMemsetAsync(w.deg, 0, sizeof(int) * (P + 4), s));
+        hipLaunchKernelGGL(p2n_rev_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, w.idx, P, N, k1, w.deg);
+        hipLaunchKernelGGL(p2n_scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, s, w.deg, P + 1, w.off, w.totals);
+        hipLaunchKernelGGL(p2n_scan_totals_kernel, dim3(1), dim3(256), 0, s, w.totals, nb, w.totals + nb);
+        hipLaunchKernelGGL(p2n_scan_add_kernel, dim3((unsigned)nb), dim3(256), 0, s, w.off, P + 1, w.totals);
+        hipLaunchKernelGGL(p2n_rev_fill_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, w.idx, P, N, k1, w.off, w.deg,
+                           w.rev);
+        const int V = (E + 63) / 64;
+        if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
+        else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
+        else if (V == 3) hipLaunchKernelGGL(p2n_smooth_pull_kernel<3>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
+        else hipLaunchKernelGGL(p2n_smooth_pull_kernel<4>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
+    } else {
+        P2N_CHECK_HIP(hipMemsetAsync(w.den, 0, sizeof(float) * P * E, s));
+        smooth_launch(true, w.en, w.idx, P, N, E, k1, smooth_scale, nullptr, w.den, (unsigned)pb, s);
+    }
     P2N_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, w.den, w.en, w.rn, P, E, demb_smooth);
     P2N_CHECK_HIP(hipGetLastError());

@@ -578,6 +578,31 @@ __global__ __launch_bounds__(256) void p2n_colsum_pm_kernel(const float *__restr
     if (threadIdx.x == 0) out[e] = u;
 }
 
+// The same sum with coalesced reads, for E dividing 256: thread t of a block always meets channel
+// t % E when it strides by 256 floats, so a block streams a contiguous slab of rows, combines its
+// 256 / E partial sums per channel in LDS and adds them to out[] (zeroed by the caller) with one
+// atomic per channel.  The column-walking form above reads 4 bytes of every 4*E-byte row from E blocks.
+#define CSUM_ROWS 2048   // rows per block
+__global__ __launch_bounds__(256) void p2n_colsum_pm_slab_kernel(const float *__restrict__ g, long P, int E,
+                                                                float *__restrict__ out) {
+    __shared__ float sh[256];
+    const long r0 = (long)blockIdx.x * CSUM_ROWS;
+    const long r1 = r0 + CSUM_ROWS < P ? r0 + CSUM_ROWS : P;
+    const float *base = g + r0 * E;
+    const long n = (r1 - r0) * E;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;   // four independent chains: loads in flight
+    long i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) { u0 += base[i]; u1 += base[i + 256]; u2 += base[i + 512]; u3 += base[i + 768]; }
+    for (; i < n; i += 256) u0 += base[i];
+    sh[threadIdx.x] = (u0 + u1) + (u2 + u3);
+    __syncthreads();
+    if ((int)threadIdx.x < E) {
+        float t = 0.f;
+        for (int k = threadIdx.x; k < 256; k += E) t += sh[k];
+        atomicAdd(&out[threadIdx.x], t);
+    }
+}
+
 // ---------------------------------------------------------------- host orchestration
 namespace {
 struct Net {
@@ -798,7 +823,13 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
     for (int l = 0; l < 8; ++l) P2N_CHECK_HIP(hipMemsetAsync(db[l], 0, sizeof(float) * n.cout[l], s));   // sum dz = 0 under BN
 
     // ---- layer 8 (no BN): dz8 = gemb
-    hipLaunchKernelGGL(p2n_colsum_pm_kernel, dim3(E), dim3(256), 0, s, gemb, (long)n.P, E, db[8]);
+    if (256 % E == 0) {
+        P2N_CHECK_HIP(hipMemsetAsync(db[8], 0, sizeof(float) * E, s));
+        hipLaunchKernelGGL(p2n_colsum_pm_slab_kernel, dim3((unsigned)((n.P + CSUM_ROWS - 1) / CSUM_ROWS)), dim3(256), 0, s, gemb,
+                           (long)n.P, E, db[8]);
+    } else {
+        hipLaunchKernelGGL(p2n_colsum_pm_kernel, dim3(E), dim3(256), 0, s, gemb, (long)n.P, E, db[8]);
+    }
     P2N_CHECK_HIP(hipGetLastError());
     {
         WgArgs w = {};
