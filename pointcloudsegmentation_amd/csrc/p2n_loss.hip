@@ -59,19 +59,7 @@ __global__ __launch_bounds__(256) void p2n_normalize_bwd_kernel(const float *den
     for (int c = lane; c < E; c += 64) out[p * E + c] = (den[p * E + c] - en[p * E + c] * s) * r;
 }
 
-// sums[inst[p]][:] += en[p][:]
-__global__ __launch_bounds__(256) void p2n_seg_sum_kernel(const float *__restrict__ en, const int *__restrict__ inst,
-                                                         const int *__restrict__ bg, long P, int E,
-                                                         float *__restrict__ sums) {
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (p >= P) return;
-    const int i = inst[p];
-    if (bg[i]) return;
-    for (int c = lane; c < E; c += 64) atomicAdd(&sums[(long)i * E + c], en[p * E + c]);
-}
-
-// Workgroup-private form of the two per-instance accumulations (seg_sum above, pull pass A below):
+// The two per-instance accumulations (instance sums, pull pass A), workgroup-private:
 // a workgroup walks SEG_CHUNK consecutive points of ONE cloud and adds into an LDS copy of that
 // cloud's instance rows (ids of a cloud are contiguous, cstart), then flushes the rows it touched
 // with one global atomic per element.  The direct form sends 64 global atomics per point to a few
@@ -248,31 +236,6 @@ __global__ __launch_bounds__(256) void p2n_disc_cloud_kernel(const float *__rest
     if (threadIdx.x == 0) push_b[b] = ninst > 1 ? loss * w : 0.f;
 }
 
-// pull pass A: per point distance to its instance mean; pullsum[i] += max(dist - delta_v, 0);
-// G[i] += u_p (unit vector towards the point where the hinge is active)
-__global__ __launch_bounds__(256) void p2n_pull_a_kernel(const float *__restrict__ en, const int *__restrict__ inst,
-                                                        const int *__restrict__ bg, const float *__restrict__ mu,
-                                                        long P, int E, float delta_v, float *__restrict__ pullsum,
-                                                        float *__restrict__ G, int want_grad) {
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (p >= P) return;
-    const int i = inst[p];
-    if (bg[i]) return;
-    float s = 0.f;
-    for (int c = lane; c < E; c += 64) { const float d = en[p * E + c] - mu[(long)i * E + c]; s = fmaf(d, d, s); }
-    s = wave_sum(s);
-    const float dist = sqrtf(s);
-    const float v = dist - delta_v;
-    if (v > 0.f) {
-        if (lane == 0) atomicAdd(&pullsum[i], v);
-        if (want_grad && dist > 0.f) {
-            const float r = 1.0f / dist;
-            for (int c = lane; c < E; c += 64) atomicAdd(&G[(long)i * E + c], (en[p * E + c] - mu[(long)i * E + c]) * r);
-        }
-    }
-}
-
 // per cloud: pull_b = sum_i (pullsum[i]/cnt[i]) / (I_b + 1e-6)          (losses.py:413-428)
 __global__ void p2n_pull_cloud_kernel(const float *__restrict__ pullsum, const int *__restrict__ cnt,
                                       const int *__restrict__ bg, const int *__restrict__ cstart, int B,
@@ -317,66 +280,6 @@ __global__ __launch_bounds__(256) void p2n_pull_b_kernel(const float *__restrict
         dpull[p * E + c] = cb * (u - G[(long)i * E + c] * rn_i);
         dpush[p * E + c] = dmu[(long)i * E + c] * rn_i;
     }
-}
-
-// ---- smoothness, generic form (any E): one neighbour at a time ----
-// smoothness forward: part[block] = sum over the block's points of sum_{j=1..k} |en[nbr_j] - en[p]|
-// (idx has k+1 columns; column 0 is dropped as the reference does, losses.py:479)
-__global__ __launch_bounds__(256) void p2n_smooth_fwd_generic_kernel(const float *__restrict__ en, const int *__restrict__ idx,
-                                                            long P, int N, int E, int k1, float *__restrict__ part) {
-    __shared__ float sh[4];
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    float acc = 0.f;
-    if (p < P) {
-        const long base = (p / N) * (long)N;
-        for (int j = 1; j < k1; ++j) {
-            const long q = base + idx[p * k1 + j];
-            float s = 0.f;
-            for (int c = lane; c < E; c += 64) { const float d = en[q * E + c] - en[p * E + c]; s = fmaf(d, d, s); }
-            s = wave_sum(s);
-            acc += sqrtf(s);
-        }
-    }
-    acc = block_sum(lane == 0 ? acc : 0.f, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-}
-
-// smoothness backward w.r.t. en: den[q] += w*(en_q - en_p)/d (atomics: q is a neighbour of many
-// points), den[p] -= the sum of the same terms (accumulated in registers, one atomic per element)
-__global__ __launch_bounds__(256) void p2n_smooth_bwd_generic_kernel(const float *__restrict__ en, const int *__restrict__ idx,
-                                                            long P, int N, int E, int k1, float w,
-                                                            float *__restrict__ den) {
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (p >= P) return;
-    const long base = (p / N) * (long)N;
-    float self[4] = {0.f, 0.f, 0.f, 0.f};   // E <= 256: up to 4 channels per lane
-    float ep[4];
-    {
-        int c4 = 0;
-        for (int c = lane; c < E; c += 64, ++c4) ep[c4] = en[p * E + c];
-    }
-    for (int j = 1; j < k1; ++j) {
-        const long q = base + idx[p * k1 + j];
-        float dq[4];
-        float s = 0.f;
-        int c4 = 0;
-        for (int c = lane; c < E; c += 64, ++c4) { dq[c4] = en[q * E + c] - ep[c4]; s = fmaf(dq[c4], dq[c4], s); }
-        s = wave_sum(s);
-        const float d = sqrtf(s);
-        if (d > 0.f) {
-            const float r = w / d;
-            c4 = 0;
-            for (int c = lane; c < E; c += 64, ++c4) {
-                const float g = dq[c4] * r;
-                atomicAdd(&den[q * E + c], g);
-                self[c4] -= g;
-            }
-        }
-    }
-    int c4 = 0;
-    for (int c = lane; c < E; c += 64, ++c4) atomicAdd(&den[p * E + c], self[c4]);
 }
 
 // ---- smoothness, row-parallel form (E <= 256) ------------------------------------------------
@@ -664,13 +567,7 @@ __global__ __launch_bounds__(256) void p2n_loss_finalize_kernel(const float *__r
 
 static void smooth_launch(bool bwd, const float *en, const int *idx, long P, int N, int E, int k1, float w, float *part,
                           float *den, unsigned blocks, hipStream_t s) {
-    const bool vec = E <= 256 && k1 <= 64;
-    if (!vec) {
-        if (bwd) hipLaunchKernelGGL(p2n_smooth_bwd_generic_kernel, dim3(blocks), dim3(256), 0, s, en, idx, P, N, E, k1, w, den);
-        else hipLaunchKernelGGL(p2n_smooth_fwd_generic_kernel, dim3(blocks), dim3(256), 0, s, en, idx, P, N, E, k1, part);
-        return;
-    }
-    const int V = (E + 63) / 64;
+    const int V = (E + 63) / 64;   // E <= 256, k1 <= 64 (checked by the entry point)
 #define SM_GO(VV)                                                                                                         \
     do {                                                                                                                  \
         if (bwd) hipLaunchKernelGGL((p2n_smooth_vec_kernel<VV, true>), dim3(blocks), dim3(256), 0, s, en, idx, P, N, E, k1, w, part, den); \
@@ -729,7 +626,7 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
                                      float delta_v, float delta_d, int k, float *losses, float *demb_pull,
                                      float *demb_push, float *demb_smooth, void *workspace, size_t workspace_bytes,
                                      void *stream_) {
-    P2N_REQUIRE(B >= 1 && N >= 1 && T >= 1, "p2n_instance_seg_loss: bad shape B=%d N=%d T=%d", B, N, T);
+    P2N_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && T >= 1, "p2n_instance_seg_loss: bad shape B=%d N=%d T=%d", B, N, T);
     P2N_REQUIRE(E >= 1 && E <= 256, "p2n_instance_seg_loss: embedding_dim %d not in [1,256]", E);
     P2N_REQUIRE(k >= 1 && k + 1 <= 64, "p2n_instance_seg_loss: k=%d not in [1,63]", k);
     P2N_REQUIRE(k + 1 <= N, "p2n_instance_seg_loss: k+1=%d neighbours requested from clouds of %d points", k + 1, N);
@@ -755,30 +652,21 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     // more falls back to global atomics inside the kernel); E <= 256: four channels per lane
     const int seg_cap = (int)(SEG_MAX_LDS / ((E + 1) * sizeof(float)));
     const size_t seg_lds = (size_t)seg_cap * (E + 1) * sizeof(float);
-    const bool seg_private = E <= 256 && B <= 65535 && seg_cap >= 1;
     const dim3 seg_grid((N + SEG_CHUNK - 1) / SEG_CHUNK, B);
-    if (seg_private) {
-        if (seg_lds > 48 * 1024) {
-            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_seg_lds_kernel<0>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));
-            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_seg_lds_kernel<1>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));
-        }
-        hipLaunchKernelGGL(p2n_seg_lds_kernel<0>, seg_grid, dim3(SEG_THREADS), seg_lds, s, w.en, inst, bg, cstart, (const float *)nullptr,
-                           N, E, 0.f, 0, w.sums, (float *)nullptr, seg_cap);
-    } else {
-        hipLaunchKernelGGL(p2n_seg_sum_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, P, E, w.sums);
+    if (seg_lds > 48 * 1024) {
+        P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_seg_lds_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));
+        P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_seg_lds_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));
     }
+    hipLaunchKernelGGL(p2n_seg_lds_kernel<0>, seg_grid, dim3(SEG_THREADS), seg_lds, s, w.en, inst, bg, cstart, (const float *)nullptr,
+                       N, E, 0.f, 0, w.sums, (float *)nullptr, seg_cap);
     P2N_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(p2n_disc_cloud_kernel, dim3(B), dim3(256), 0, s, w.sums, cnt, bg, cstart, E, B, delta_d, w.mu, w.nmu,
                        w.dmu, w.push_b, want ? 1 : 0);
     P2N_CHECK_HIP(hipGetLastError());
-    if (seg_private)
-        hipLaunchKernelGGL(p2n_seg_lds_kernel<1>, seg_grid, dim3(SEG_THREADS), seg_lds, s, w.en, inst, bg, cstart, w.mu, N, E, delta_v,
-                           want ? 1 : 0, w.G, w.pullsum, seg_cap);
-    else
-        hipLaunchKernelGGL(p2n_pull_a_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, w.mu, P, E, delta_v, w.pullsum, w.G,
-                           want ? 1 : 0);
+    hipLaunchKernelGGL(p2n_seg_lds_kernel<1>, seg_grid, dim3(SEG_THREADS), seg_lds, s, w.en, inst, bg, cstart, w.mu, N, E, delta_v,
+                       want ? 1 : 0, w.G, w.pullsum, seg_cap);
     P2N_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(p2n_pull_cloud_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.pullsum, cnt, bg, cstart, B, w.pull_b,
                        w.coef);

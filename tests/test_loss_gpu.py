@@ -37,7 +37,10 @@ def test_loss_matches_reference_golden():
     assert d.max() / np.abs(ref).max() < 2e-2
 
 
-@pytest.mark.parametrize("B,N,E,ninst", [(2, 500, 64, 7), (3, 1000, 32, 33), (1, 2048, 64, 2), (2, 300, 100, 5)])
+@pytest.mark.parametrize("B,N,E,ninst", [(2, 500, 64, 7), (3, 1000, 32, 33), (1, 2048, 64, 2), (2, 300, 100, 5),
+                                         (2, 1500, 256, 80),   # more instance rows than the LDS copy holds: global-atomic path
+                                         (1, 700, 20, 9),      # channel count that is no multiple of 16
+                                         (2, 1030, 200, 3)])   # four channels per lane, chunk tail
 def test_loss_matches_oracle(B, N, E, ninst):
     from oracle import loss_oracle
     from pointcloudsegmentation_amd.synth import make_batch, make_labels
