@@ -37,6 +37,8 @@ typedef __bf16 cl_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void cl_lds_void;
 typedef const __attribute__((address_space(1))) void cl_gbl_void;
 
+// s_waitcnt vmcnt(n) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+#define CL_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (0 << 8) | (((n) >> 4) << 14))
 #define CL_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define CL_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
@@ -180,7 +182,7 @@ struct ClArgs {
     int *nbr_cnt, *nbr;     // pass 2: core neighbours of non-core rows, `cap` slots per row
     int cap;
     int nsplit;
-    const int *act_cnt;     // per 128-point row block: number of active 128-point blocks
+    const int *act_cnt;     // per 256-point row block (one workgroup): number of active 128-point blocks
     const int *act_list;    // [row block][nb128]: their indices, ascending
     int nb128;
     unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
@@ -197,16 +199,17 @@ struct ClArgs {
 // Software pipeline over "units" of UT streamed tiles: the MFMAs of one unit are issued
 // interleaved with the compares of the previous unit (two small accumulator sets).
 #define CL_BLK_FLOATS (8192 + 128)   // 32 fragments + nh[128] per LDS buffer
-#define CL_PAR_BASE (2 * CL_BLK_FLOATS)   // then three rotating parent[128] slots (pass 2)
+#define CL_RING 3                          // streamed blocks resident in LDS: one in use, two in flight
+#define CL_PAR_BASE (CL_RING * CL_BLK_FLOATS)   // then three rotating parent[128] slots (pass 2)
 #define CL_LDS_FLOATS (CL_PAR_BASE + 3 * 128)
 #define CL_SLIST_MAX 2048   // active-list entries one workgroup may hold in LDS (after the ring)
 
-#define CL_NW 4   // waves per workgroup: 128 wave-owned points share one streamed block (6 or 8 waves spill: measured slower)
+#define CL_NW 8   // waves per workgroup, one workgroup per CU: 256 wave-owned points share one streamed block
 #define CL_ROWBLK (CL_NW * 32)
-#define CL_NPAD_UNIT 128   // lcm(CL_ROWBLK, 128): rows pad to whole workgroups and whole streamed blocks
+#define CL_NPAD_UNIT 256   // lcm(CL_ROWBLK, 128): rows pad to whole workgroups and whole streamed blocks
 
 template <int G, int CT, int MODE>
-__global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
+__global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   // 512 threads, one workgroup per CU, 2 waves per SIMD
     extern __shared__ __attribute__((aligned(16))) float lds[];   // CL_LDS_FLOATS
     static_assert(G * CT == 32, "a streamed block is 32 fragments");
     constexpr int JB = CT * 32;
@@ -236,13 +239,11 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
 
     auto stage = [&](long jb, int buf) {
         float *dst = lds + buf * CL_BLK_FLOATS;
-        if (wave < 4) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int f = wave * 8 + q;
-                __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xb + (jb * 32 + f) * 256 + lane * 4),
-                                                 (cl_lds_void *)(dst + f * 256), 16, 0, 0);
-            }
+        for (int q = 0; q < 32 / CL_NW; ++q) {
+            const int f = wave * (32 / CL_NW) + q;
+            __builtin_amdgcn_global_load_lds((cl_gbl_void *)(A.Xb + (jb * 32 + f) * 256 + lane * 4),
+                                             (cl_lds_void *)(dst + f * 256), 16, 0, 0);
         }
         // nh and (pass 2) parent of the block's JB points: waves 0/1 (2/3) move 64 dwords each
         if (wave * 64 < JB)
@@ -260,8 +261,12 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
     long jb_now = jbof(cur);
     long jb_nxt = jbof(cur + 1 == len ? 0 : cur + 1);
     stage(jb_now, 0);
+    if (len > 1) stage(jb_nxt, 1);
+    // LDS-DMA instructions one stage() issues from this wave: what may stay in flight at a block entry
+    const bool dma5 = wave * 64 < JB;
     if (pfetch) lds[pslot] = __int_as_float(CL_LD(A.parent + jb_now * JB + (wave - 2) * 64 + lane));
     int pnext = 0;
+    int pi_nxt = MODE == 1 ? CL_LD(A.parent + (((long)blockIdx.x * CL_NW + wave) * 32 + (lane & 31))) : 0;
 
     constexpr int KS = G / 2;             // k-steps of 16
     constexpr int NSL = 3 * KS;           // MFMA slots per tile: hi.hi, hi.lo, lo.hi per k-step
@@ -368,10 +373,25 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
                 const long nxt = (cur + 1 == len) ? 0 : cur + 1;
                 const long nn = (nxt + 1 == len) ? 0 : nxt + 1;
                 const long jb_after = jbof(nn);
-                p2n_dma_barrier();   // block jb_cur has landed (explicit vmcnt(0) + barrier); the other buffer is free
-                if (MODE == 1) pi = CL_LD(A.parent + my);   // queued before the DMA: vmcnt completes in order
+                // Block t has landed once at most the DMA instructions of block t+1 (this wave's share, the
+                // youngest loads it has issued) are still in flight: vector-memory loads retire in issue
+                // order, and anything else the wave has queued only makes the wait stricter.  The barrier
+                // then publishes every wave's share and proves that all waves have left block t-1, whose
+                // ring slot block t+2 takes.
+                if (t + 1 < len) {
+                    if (dma5) CL_WAIT_VMCNT(32 / CL_NW + 1);
+                    else CL_WAIT_VMCNT(32 / CL_NW);
+                } else {
+                    CL_WAIT_VMCNT(0);
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (MODE == 1) {   // own parent, one block stale: the filter below only needs SOME past ancestor of `my`
+                    pi = pi_nxt;
+                    pi_nxt = CL_LD(A.parent + my);
+                }
                 if (pfetch && t + 1 < len) pnext = CL_LD(A.parent + jb_nxt * JB + (wave - 2) * 64 + lane);
-                if (t + 1 < len) stage(jb_nxt, (int)((t + 1) & 1));
+                if (t + 2 < len) stage(jb_after, (int)((t + 2) % CL_RING));
                 cur = nxt;
                 jb_now = jb_nxt;
                 jb_nxt = jb_after;
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {
             }
             active = blk_active;
         }
-        const float *blk = lds + (t & 1) * CL_BLK_FLOATS;
+        const float *blk = lds + (int)(t % CL_RING) * CL_BLK_FLOATS;
         const float *ubuf = blk + u * UT * G * 256;
         const long col0 = jb_cur * JB + u * UT * 32;
         const int before = cntm;
@@ -469,29 +489,34 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     if (t < 8 * G) centre[(long)b * 8 * G + t] = cen[t];
 }
 
-// grid = row blocks.  list[ib][0..cnt) = column blocks jb (ascending) with |c_ib - c_jb| <= r_ib + r_jb + eps.
+// grid = row groups of 256 points.  list[ib][0..cnt) = column blocks jb (ascending) that can reach either of the
+// group's two 128-point blocks: |c - c_jb| <= r + r_jb + eps.
 __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict__ centre, const float *__restrict__ radius,
                                                         int nb, int Dp, float eps, int *__restrict__ act_cnt,
                                                         int *__restrict__ act_list) {
-    extern __shared__ float ci[];   // [Dp] own centre, then [256] ints scan scratch
-    int *scan = reinterpret_cast<int *>(ci + Dp);
+    extern __shared__ float ci[];   // [2][Dp] the centres of the row group's two 128-point blocks, then [256] ints scan scratch
+    int *scan = reinterpret_cast<int *>(ci + 2 * Dp);
     __shared__ int base;
-    const int ib = blockIdx.x, t = threadIdx.x;
-    for (int k = t; k < Dp; k += 256) ci[k] = centre[(long)ib * Dp + k];
+    const int ib = blockIdx.x, t = threadIdx.x;   // ib: a workgroup's 256 rows = 128-point blocks 2 ib and 2 ib + 1
+    for (int k = t; k < 2 * Dp; k += 256) ci[k] = centre[(long)2 * ib * Dp + k];
     if (t == 0) base = 0;
     __syncthreads();
-    const float ri = radius[ib];
+    const float ri0 = radius[2 * ib], ri1 = radius[2 * ib + 1];
     for (int j0 = 0; j0 < nb; j0 += 256) {
         const int jb = j0 + t;
         int act = 0;
-        if (jb < nb && ri >= 0.f) {
+        if (jb < nb) {
             const float rj = radius[jb];
             if (rj >= 0.f) {
-                float d2 = 0.f;
+                float d20 = 0.f, d21 = 0.f;
                 const float *cj = centre + (long)jb * Dp;
-                for (int k = 0; k < Dp; ++k) { const float d = ci[k] - cj[k]; d2 = fmaf(d, d, d2); }
-                const float reach = ri + rj + eps + CL_SPH_MARGIN;
-                act = d2 <= reach * reach;
+                for (int k = 0; k < Dp; ++k) {
+                    const float c = cj[k], d0 = ci[k] - c, d1 = ci[Dp + k] - c;
+                    d20 = fmaf(d0, d0, d20);
+                    d21 = fmaf(d1, d1, d21);
+                }
+                const float reach0 = ri0 + rj + eps + CL_SPH_MARGIN, reach1 = ri1 + rj + eps + CL_SPH_MARGIN;
+                act = (ri0 >= 0.f && d20 <= reach0 * reach0) || (ri1 >= 0.f && d21 <= reach1 * reach1);
             }
         }
         scan[t] = act;
@@ -654,7 +679,7 @@ extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, v
 
 template <int G, int CT>
 static int cl_launch_pairs(int mode, const ClArgs &a, long nrowblk, hipStream_t stream) {
-    const size_t ldsb = (CL_LDS_FLOATS + CL_SLIST_MAX) * sizeof(float);   // 76 KiB: above the default dynamic-LDS limit
+    const size_t ldsb = (CL_LDS_FLOATS + CL_SLIST_MAX) * sizeof(float);   // 107 KiB: above the default dynamic-LDS limit
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 1>),
@@ -693,7 +718,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const int nb128 = (int)(Npad / 128);
     hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (8 * G + 128), stream, w.Xp, w.nrm, G, w.centre,
                        w.radius);
-    hipLaunchKernelGGL(cl_active_kernel, dim3(nb128), dim3(256), sizeof(float) * (8 * G + 256), stream, w.centre, w.radius, nb128,
+    hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
                        8 * G, (float)eps, w.act_cnt, w.act_list);
     P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
