@@ -125,20 +125,30 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------ exact pair test
+#define CL_EX_BATCH 4
+// The 2 * G 16-byte pieces of both rows are fetched CL_EX_BATCH steps at a time (loads in flight, then
+// that stretch of the sum): fetched and consumed one step at a time the test was a chain of
+// 2 G dependent memory round trips, and a wave in it holds up its whole workgroup at the next barrier.
 __device__ __forceinline__ bool cl_exact_within(const float *__restrict__ Xp, int G, long i, long j, double eps2) {
     const float *pa = Xp + ((i >> 5) * G * 64 + (i & 31)) * 4;
     const float *pb = Xp + ((j >> 5) * G * 64 + (j & 31)) * 4;
     double s = 0.0;
-    for (int g = 0; g < G; ++g)
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(pa + g * 256 + h * 128);
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(pb + g * 256 + h * 128);
+    for (int st0 = 0; st0 < 2 * G; st0 += CL_EX_BATCH) {   // step st = 2 g + h: dims 4 st .. 4 st + 3, ascending
+        f32x4 a[CL_EX_BATCH], b[CL_EX_BATCH];
+#pragma unroll
+        for (int u = 0; u < CL_EX_BATCH; ++u) {
+            const int st = st0 + u, g = st >> 1, h = st & 1;
+            a[u] = *reinterpret_cast<const f32x4 *>(pa + g * 256 + h * 128);
+            b[u] = *reinterpret_cast<const f32x4 *>(pb + g * 256 + h * 128);
+        }
+#pragma unroll
+        for (int u = 0; u < CL_EX_BATCH; ++u)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double d = (double)a[q] - (double)b[q];
+                const double d = (double)a[u][q] - (double)b[u][q];
                 s += d * d;   // -ffp-contract=off: separate multiply and add, as the oracle
             }
-        }
+    }
     return s <= eps2;
 }
 
@@ -186,6 +196,10 @@ struct ClArgs {
     const int *act_list;    // [row block][nb128]: their indices, ascending
     int nb128;
     unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
+    // pass 1: undecided pairs are queued per lane ([wave][slot][lane] = partner index) and decided by
+    // cl_resolve_kernel afterwards; a lane whose queue is full decides on the spot
+    int *defer_q, *defer_cnt;
+    int defer_cap;
 };
 
 // Orientation: D = X_J . X_I^T -- the streamed points j are the ROWS of the MFMA result (one per
@@ -279,6 +293,8 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     const float hh = -A.nrm_row[my] - 0.5f * A.eps2f;   // nrm_* hold -|x|^2/2 (-inf on pad rows: h = +inf, nothing reaches it)
     const float hm = hh - 0.5f * A.tau, hd = hh + 0.5f * A.tau;
     const bool mycore = MODE == 1 && A.core[my];
+    int dq_n = 0;   // pass 1: queued undecided pairs of this lane
+    const long dq_wave = ((long)blockIdx.y * gridDim.x + blockIdx.x) * CL_NW + wave;
     int cntd = 0, cntm = 0, expdiff = 0;   // pass 1: definite(+resolved) / maybe counts; pass 2: cntm = maybe-edges seen
     int pi = 0;
 
@@ -335,8 +351,13 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             const int ut = e >> 4, r = e & 15;
             const long other = col0 + ut * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
             if (MODE == 0) {
-                atomicAdd(A.stats + 0, 1ull);
-                cntd += cl_exact_within(A.Xp, G, my, other, A.eps2);
+                if (dq_n < A.defer_cap) {
+                    A.defer_q[(dq_wave * A.defer_cap + dq_n) * 64 + lane] = (int)other;
+                    ++dq_n;
+                } else {
+                    atomicAdd(A.stats + 0, 1ull);
+                    cntd += cl_exact_within(A.Xp, G, my, other, A.eps2);
+                }
             } else {
                 bool ok = sure >> e & 1;
                 if (!ok) {
@@ -443,6 +464,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         if (w + 1 <= W) unit_step(accB, accA, w + 1, std::integral_constant<int, (UPS > 1 ? 1 : 0)>{});
     }
     if (MODE == 0) {
+        A.defer_cnt[dq_wave * 64 + lane] = dq_n;
         cntd += __shfl_xor(cntd, 32);   // the two lane halves saw different rows of the same point
         if (h == 0 && cntd) atomicAdd(A.cnt + my, cntd);
     }
@@ -535,6 +557,28 @@ __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict_
     if (t == 0) act_cnt[ib] = base;
 }
 
+// ------------------------------------------------------------------ deferred exact tests of pass 1
+// One thread per queue slot ([wave][slot][lane]).  The pair passes run their 8 waves in lockstep (a
+// barrier per streamed block), so a wave that stops for a float64 test -- two dependent memory round
+// trips -- stalls seven others; 94 % of the blocks had such a wave.  Queued, the tests run here, all
+// in flight at once.
+__global__ __launch_bounds__(256) void cl_resolve_kernel(const float *__restrict__ Xp, int G, double eps2,
+                                                         const int *__restrict__ q, const int *__restrict__ qcnt, int cap,
+                                                         long nwaves, int nrowblk, int *__restrict__ cnt,
+                                                         unsigned long long *__restrict__ stats) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;   // ((wave * cap) + slot) * 64 + lane
+    const int lane = (int)(e & 63);
+    const long ws = e >> 6;
+    const long wave = ws / cap;
+    const int slot = (int)(ws % cap);
+    if (wave >= nwaves || slot >= qcnt[wave * 64 + lane]) return;
+    const long wg = wave / CL_NW;                          // blockIdx.y * gridDim.x + blockIdx.x of the pair pass
+    const long my = ((wg % nrowblk) * CL_NW + wave % CL_NW) * 32 + (lane & 31);
+    const long other = q[e];
+    atomicAdd(stats + 0, 1ull);
+    if (cl_exact_within(Xp, G, my, other, eps2)) atomicAdd(cnt + my, 1);
+}
+
 // ------------------------------------------------------------------ glue kernels
 // after pass 1: core flags, column norms with non-core masked out, union-find initial state
 __global__ __launch_bounds__(256) void cl_prepare_link_kernel(const int *__restrict__ cnt, const float *__restrict__ nrm, long N,
@@ -612,7 +656,21 @@ struct ClWs {
     unsigned long long *stats;
     float *centre, *radius;
     int *act_cnt, *act_list;
+    int *defer_q, *defer_cnt;
+    long defer_waves;
 };
+
+#define CL_DEFER_CAP 16   // queued undecided pairs per lane (pass 1); beyond that a lane decides on the spot
+
+// column splits of the pair passes: enough workgroups to fill the chip several times, a list slice must fit in LDS
+static int cl_nsplit(long Npad, int G) {
+    const int CT = 32 / G;
+    const long nrowblk = Npad / CL_ROWBLK, ncolblk = Npad / (CT * 32), nb128 = Npad / 128;
+    long ns = (2048 + nrowblk - 1) / nrowblk;
+    ns = ns < 1 ? 1 : (ns > ncolblk ? ncolblk : ns);
+    if (ns * CL_SLIST_MAX < nb128) ns = (nb128 + CL_SLIST_MAX - 1) / CL_SLIST_MAX;
+    return (int)ns;
+}
 
 static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
     size_t o = 0;
@@ -640,6 +698,9 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         w.act_list = (int *)take(sizeof(int) * nb * nb);
     }
     w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
+    w.defer_waves = (Npad / CL_ROWBLK) * cl_nsplit(Npad, G) * CL_NW;
+    w.defer_q = (int *)take(sizeof(int) * (size_t)w.defer_waves * CL_DEFER_CAP * 64);
+    w.defer_cnt = (int *)take(sizeof(int) * (size_t)w.defer_waves * 64);
     return o;
 }
 
@@ -721,6 +782,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
                        8 * G, (float)eps, w.act_cnt, w.act_list);
     P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
+    P2N_CHECK_HIP(hipMemsetAsync(w.defer_cnt, 0, sizeof(int) * (size_t)w.defer_waves * 64, stream));   // workgroups without work write nothing
     P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.blk_has_core, 0, sizeof(int) * (Npad / 128 + 1), stream));
     p2n_prof_end(ps, stream);
@@ -735,10 +797,8 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     a.cnt = w.cnt; a.parent = w.parent; a.core = w.core; a.colblk_has_core = w.blk_has_core;
     a.nbr_cnt = w.nbr_cnt; a.nbr = w.nbr; a.cap = cap; a.stats = w.stats;
     const long nrowblk = Npad / CL_ROWBLK;
-    long ns = (2048 + nrowblk - 1) / nrowblk;            // enough workgroups to fill 256 CUs x 2 several times
-    const long ncolblk = Npad / (CT * 32);
-    a.nsplit = (int)(ns < 1 ? 1 : (ns > ncolblk ? ncolblk : ns));
-    if ((long)a.nsplit * CL_SLIST_MAX < nb128) a.nsplit = (int)((nb128 + CL_SLIST_MAX - 1) / CL_SLIST_MAX);   // a list slice must fit in LDS
+    a.nsplit = cl_nsplit(Npad, G);
+    a.defer_q = w.defer_q; a.defer_cnt = w.defer_cnt; a.defer_cap = CL_DEFER_CAP;
     a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128;
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
@@ -748,6 +808,13 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     p2n_prof_end(ps, stream);
     if (rc) return rc;
 
+    {   // the queued float64 decisions of pass 1 (every lane of the pass wrote its queue length)
+        const long slots = w.defer_waves * CL_DEFER_CAP * 64;
+        ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
+        hipLaunchKernelGGL(cl_resolve_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, w.Xp, G, a.eps2,
+                           w.defer_q, w.defer_cnt, CL_DEFER_CAP, w.defer_waves, (int)nrowblk, w.cnt, w.stats);
+        p2n_prof_end(ps, stream);
+    }
     hipLaunchKernelGGL(cl_prepare_link_kernel, dim3(nb256), dim3(256), 0, stream, w.cnt, w.nrm, N, Npad, min_samples, w.core,
                        w.nrm_core, w.parent, w.nbr_cnt, w.blk_has_core);
     a.nrm_col = w.nrm_core;
