@@ -7,6 +7,7 @@ leaving the device between them.  File IO, PLY writers and visualisation stay wi
 import numpy as np
 import torch
 
+from . import runtime as _rt
 from .clustering import cluster_embeddings
 from .preprocess import preprocess_point_cloud
 
@@ -28,7 +29,7 @@ def predict(model, points, colors=None, eps: float = 0.1, min_samples: int = 50,
     # reference inference.py:183: len(np.unique(labels)) - 1, whether or not a noise label occurs
     num = int(torch.unique(labels).numel()) - 1
     if to_host:
-        labels, emb = labels.cpu().numpy(), emb.cpu().numpy()
+        labels, emb = _rt.download(labels, emb)   # pinned staging, one synchronisation
     return {"instance_labels": labels, "embeddings": emb, "num_instances": num, "centroid": centroid, "scale": scale}
 
 

@@ -15,7 +15,7 @@ def _f64_device(a, name):
     if isinstance(a, np.ndarray):
         if not torch.cuda.is_available():
             raise RuntimeError("preprocess_point_cloud: needs a GPU (the HIP library is the only implementation)")
-        a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+        a = _rt.upload(a, torch.float64, torch.device("cuda", torch.cuda.current_device()))
     if not (isinstance(a, torch.Tensor) and a.is_cuda):
         raise ValueError(f"{name} must be a numpy array or a GPU tensor")
     a = a.to(torch.float64).contiguous()

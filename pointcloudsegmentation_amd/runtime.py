@@ -31,6 +31,30 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     return buf
 
 
+def upload(a, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """numpy array -> GPU tensor through a pinned staging buffer (torch's caching host allocator
+    hands the block back on later calls), so the copy is one DMA instead of the driver's pageable
+    path; ordered on the current stream."""
+    import numpy as np
+    src = torch.from_numpy(np.ascontiguousarray(a))
+    stage = torch.empty(src.shape, dtype=dtype, pin_memory=True)
+    stage.copy_(src)                       # host-side conversion + copy into pinned memory
+    return stage.to(device, non_blocking=True)
+
+
+def download(*tensors: torch.Tensor):
+    """GPU tensors -> numpy arrays backed by pinned host memory: all copies are queued, then one
+    synchronisation.  The arrays own their pinned blocks (returned to torch's host cache when they die)."""
+    outs = []
+    for t in tensors:
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        outs.append(h)
+    if tensors:
+        torch.cuda.current_stream(tensors[0].device).synchronize()
+    return tuple(h.numpy() for h in outs)
+
+
 def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise ValueError(f"{name} must be a GPU tensor")
