@@ -9,6 +9,18 @@
 #include <stdlib.h>
 #include "p2n_common.h"
 
+// Tuning overrides for the sweep tools (tools/fps_sweep.py, tools/sweep_gather.sh), read from the
+// environment once per process: 0 / unset = the built-in choice.
+struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off; };
+static const P2nTuning &p2n_tuning() {
+    static const P2nTuning t = [] {
+        auto num = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
+        return P2nTuning{num("P2N_FPS_G"), num("P2N_GL_CH"), num("P2N_GL_THREADS"), num("P2N_GL_SPLIT"),
+                         getenv("P2N_GL_OFF") ? 1 : 0};
+    }();
+    return t;
+}
+
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -258,8 +270,7 @@ static FpsPlan fps_plan(int B, int N) {
         }
         p.T = 1024;
     }
-    if (const char *e = getenv("P2N_FPS_G")) {   // tuning override (tools/fps_sweep.py)
-        const int g = atoi(e);
+    if (const int g = p2n_tuning().fps_g) {   // tuning override (tools/fps_sweep.py)
         if (g >= 1 && g <= gmax) {
             const int chunk = (N + g - 1) / g;
             if (chunk <= FPS_LDS_POINTS) { G = g; p.T = 256; }
@@ -711,14 +722,12 @@ static GlGeom gl_geometry(bool interp, int B, int C, long row_floats, long cols4
     const int ch_min = interp ? 4 : 1;   // the interpolation kernel reads channel quads from LDS
     for (int ch = interp ? 8 : 2; ch >= ch_min; ch >>= 1)
         if (ch * row_bytes <= GL_MAX_LDS / 2 || (ch == ch_min && ch * row_bytes <= GL_MAX_LDS)) { g.ch = ch; break; }
-    if (const char *e = getenv("P2N_GL_CH")) {
-        const int ch = atoi(e);
+    if (const int ch = p2n_tuning().gl_ch) {
         if ((ch == 1 || ch == 2 || ch == 4 || ch == 8 || ch == 16) && ch * row_bytes <= GL_MAX_LDS) g.ch = ch;
     }
     if (g.ch == 0) return g;
     while (g.ch > ch_min && g.ch / 2 >= C) g.ch >>= 1;
-    if (const char *e = getenv("P2N_GL_THREADS")) {
-        const int t = atoi(e);
+    if (const int t = p2n_tuning().gl_threads) {
         if (t == 256 || t == 512 || (t == 1024 && !interp)) g.threads = t;
     }
     const long groups = (long)B * ((C + g.ch - 1) / g.ch);
@@ -726,8 +735,7 @@ static GlGeom gl_geometry(bool interp, int B, int C, long row_floats, long cols4
     const long max_split = cols4 / (4L * g.threads);   // keep >= 4 column quads per thread
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
-    if (const char *e = getenv("P2N_GL_SPLIT")) {
-        const int sp = atoi(e);
+    if (const int sp = p2n_tuning().gl_split) {
         if (sp >= 1 && sp <= 65535) split = sp;
     }
     if (split > 65535) split = 65535;
@@ -746,7 +754,7 @@ static hipError_t gl_allow_lds(K kernel, size_t bytes) {
 static int gather_lds_launch(const float *feat, const int32_t *idx, int B, int C, int N, long MS, float *out, int CC,
                              int coff, hipStream_t stream) {
     if (N % 4 || MS % 4 || ((((uintptr_t)feat | (uintptr_t)idx | (uintptr_t)out)) & 15)) return 0;
-    if (getenv("P2N_GL_OFF")) return 0;
+    if (p2n_tuning().gl_off) return 0;
     const GlGeom g = gl_geometry(false, B, C, N, MS / 4);
     if (g.ch == 0 || g.ch > 8) return 0;
     const int quads_per_split = (int)((MS / 4 + g.split - 1) / g.split);
@@ -1006,7 +1014,7 @@ __global__ __launch_bounds__(512) void p2n_three_interp_lds_kernel(const float *
 static int interp_lds_launch(const float *feat, const int32_t *idx, const float *w, int B, int C, int m, int n,
                              float *out, hipStream_t stream) {
     if (m % 4 || n % 4 || ((((uintptr_t)feat | (uintptr_t)idx | (uintptr_t)w | (uintptr_t)out)) & 15)) return 0;
-    if (getenv("P2N_GL_OFF")) return 0;
+    if (p2n_tuning().gl_off) return 0;
     const GlGeom g = gl_geometry(true, B, C, m, n / 4);
     if (g.ch != 4 && g.ch != 8) return 0;
     const int quads_per_split = (n / 4 + g.split - 1) / g.split;
