@@ -205,6 +205,9 @@ int p2n_preprocess_points(const double *points, const double *colors, long N, fl
  * 2 head, 3 fps, 5 knn, 10 cluster prep, 11 cluster count pass, 12 cluster link pass), the summed milliseconds and the number of launches since
  * the last collect.  HOST pointers.  Not thread-safe; off by default. */
 int p2n_profile_enable(int on);
+/* kernel_id >= 0: only that kernel's launches are bracketed (two event records per step instead of
+ * two per kernel: the events themselves cost about 3 us each on the launch stream); -1 = all. */
+int p2n_profile_select(int kernel_id);
 int p2n_profile_collect(int max_ids, float *ms_sum_host, int *count_host);
 
 #ifdef __cplusplus

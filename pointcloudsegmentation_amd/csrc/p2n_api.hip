@@ -20,6 +20,7 @@ extern "C" int p2n_version(void) { return 100; }
 // summed duration and launch count per kernel id.  Not thread-safe; off by default.
 #define P2N_PROF_MAX 8192
 static bool g_prof_on = false;
+static int g_prof_sel = -1;   // >= 0: only launches of this kernel id are bracketed
 static int g_prof_n = 0;
 static hipEvent_t g_prof_ev[P2N_PROF_MAX][2];
 static int g_prof_id[P2N_PROF_MAX];
@@ -27,6 +28,7 @@ static int g_prof_created = 0;
 
 int p2n_prof_begin(int kernel_id, hipStream_t s) {
     if (!g_prof_on || g_prof_n >= P2N_PROF_MAX) return -1;
+    if (g_prof_sel >= 0 && kernel_id != g_prof_sel) return -1;
     const int i = g_prof_n;
     if (i >= g_prof_created) {
         if (hipEventCreate(&g_prof_ev[i][0]) != hipSuccess || hipEventCreate(&g_prof_ev[i][1]) != hipSuccess) return -1;
@@ -46,6 +48,11 @@ void p2n_prof_end(int slot, hipStream_t s) {
 extern "C" int p2n_profile_enable(int on) {
     g_prof_on = on != 0;
     g_prof_n = 0;
+    return P2N_OK;
+}
+
+extern "C" int p2n_profile_select(int kernel_id) {
+    g_prof_sel = kernel_id;
     return P2N_OK;
 }
 
