@@ -134,6 +134,14 @@ int p2n_ball_query(const float *xyz, const float *new_xyz, int B, int N, int M,
  * drops).  1 <= k <= 64, k <= N. */
 int p2n_knn(const float *query, const float *ref, int B, int M, int N, int k,
             int32_t *idx, float *d2, void *stream);
+/* The same search when the queries ARE the cloud (reference losses.py:475-479 calls
+ * cdist(points, points)): xyz (B,N,3) -> idx (B,N,k), d2 (B,N,k) or NULL, results identical
+ * to p2n_knn(xyz, xyz, B, N, N, k, ...).  Clouds of up to 16384 points are searched through a
+ * Morton-ordered copy with one bounding box per 64 points held in `workspace`; larger ones
+ * take p2n_knn's streaming kernel. */
+size_t p2n_knn_self_workspace_bytes(int B, int N);
+int p2n_knn_self(const float *xyz, int B, int N, int k, int32_t *idx, float *d2,
+                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* Grouping gather: feat (B,C,N), idx (B,M,ns) -> out (B,C,M,ns). */
 int p2n_group_gather(const float *feat, const int32_t *idx, int B, int C, int N, int M, int ns,

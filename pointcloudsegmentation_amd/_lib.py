@@ -43,6 +43,8 @@ SIGNATURES = {
     "p2n_fps": (c_int, [c_f, c_int, c_int, c_int, c_int, c_i, c_vp, c_sz, c_vp]),
     "p2n_ball_query": (c_int, [c_f, c_f, c_int, c_int, c_int, c_float, c_int, c_i, c_vp]),
     "p2n_knn": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_i, c_f, c_vp]),
+    "p2n_knn_self_workspace_bytes": (c_sz, [c_int, c_int]),
+    "p2n_knn_self": (c_int, [c_f, c_int, c_int, c_int, c_i, c_f, c_vp, c_sz, c_vp]),
     "p2n_group_gather": (c_int, [c_f, c_i, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]),
     "p2n_group_gather_bwd": (c_int, [c_f, c_i, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]),
     "p2n_three_nn": (c_int, [c_f, c_f, c_int, c_int, c_int, c_f, c_i, c_f, c_vp]),

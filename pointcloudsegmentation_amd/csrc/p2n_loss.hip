@@ -585,9 +585,11 @@ namespace {
 struct LossWs {
     float *en, *rn, *sums, *mu, *nmu, *dmu, *G, *pullsum, *pull_b, *push_b, *coef, *spart, *den;
     int *idx, *deg, *off, *rev, *totals;
-    size_t total;
+    char *knn_ws;
+    size_t knn_bytes, total;
 };
 size_t loss_carve(LossWs &w, char *base, long P, int E, int T, int B, int k1) {
+    const int N = (int)(P / B);
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
     w.en = (float *)take(sizeof(float) * P * E);
@@ -608,6 +610,8 @@ size_t loss_carve(LossWs &w, char *base, long P, int E, int T, int B, int k1) {
     w.off = (int *)take(sizeof(int) * (P + 4));
     w.rev = (int *)take(sizeof(int) * P * k1);
     w.totals = (int *)take(sizeof(int) * ((P + 1023) / 1024 + 4));
+    w.knn_bytes = p2n_knn_self_workspace_bytes(B, N);   // Morton-ordered copy + tile boxes of the neighbour search
+    w.knn_ws = take(w.knn_bytes);
     return off;
 }
 }  // namespace
@@ -671,8 +675,8 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     hipLaunchKernelGGL(p2n_pull_cloud_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.pullsum, cnt, bg, cstart, B, w.pull_b,
                        w.coef);
     P2N_CHECK_HIP(hipGetLastError());
-    // smoothness: brute-force kNN of every point within its cloud (k+1 incl. the point itself)
-    int rc = p2n_knn(points, points, B, N, N, k1, w.idx, nullptr, stream_);
+    // smoothness: exact kNN of every point within its own cloud (k+1 incl. the point itself)
+    int rc = p2n_knn_self(points, B, N, k1, w.idx, nullptr, w.knn_ws, w.knn_bytes, stream_);
     if (rc) return rc;
     smooth_launch(false, w.en, w.idx, P, N, E, k1, 0.f, w.spart, nullptr, (unsigned)pb, s);
     P2N_CHECK_HIP(hipGetLastError());

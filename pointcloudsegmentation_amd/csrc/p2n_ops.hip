@@ -569,6 +569,322 @@ extern "C" int p2n_knn(const float *query, const float *ref, int B, int M, int N
     return knn_launch(query, ref, B, M, N, k, idx, d2, nullptr, (hipStream_t)stream);
 }
 
+// --------------------------------------------------------------------------- self kNN (query set == cloud)
+// The smoothness loss searches every point's neighbours inside its own cloud.  Scanning all N
+// candidates per query is N^2 distance tests plus ~k*ln(N/k) list insertions; here the cloud is
+// first put in Morton-cell order (one workgroup per cloud, counting sort through an LDS histogram)
+// with a bounding box per 64-point tile; a wave seeds its two (adjacent, hence nearby) queries' lists
+// with one 64-key bitonic sort of their own tile and then visits only the tiles whose box can still
+// hold a point within the current k-th distance of either query.
+// The order of the copy affects speed only: results are the k smallest (d2, index) pairs in
+// lexicographic order whatever the visiting order, and the box bound is computed with the same
+// ((ex*ex + ey*ey) + ez*ez) roundings as the point distance, so by monotonicity of IEEE rounding it
+// never exceeds the computed distance of a point inside the box.
+#define KS_THREADS 1024
+#define KS_MAX_N 16384      // points of one cloud held in the sorting workgroup's registers (16 per thread)
+#define KS_PPT (KS_MAX_N / KS_THREADS)
+#define KS_AXIS_BITS 5      // Morton cells: 32 x 32 x 32 over the cloud's bounding box
+#define KS_BINS (1 << (3 * KS_AXIS_BITS))
+#define KS_BIN_WORDS (KS_BINS + KS_BINS / 32)   // one pad word per 32 bins: a thread's 32 consecutive bins are conflict-free
+#define KSW 4               // waves per workgroup of the search kernel (no LDS, no barriers)
+
+__device__ __forceinline__ unsigned morton_spread5(unsigned v) {   // bits 0..4 -> bits 0,3,6,9,12
+    v = (v | (v << 8)) & 0x0000100Fu;
+    v = (v | (v << 4)) & 0x000010C3u;
+    v = (v | (v << 2)) & 0x00001249u;
+    return v;
+}
+
+// Counting sort of one cloud by Morton cell (one workgroup per cloud; the cloud stays in registers
+// between the passes): bounding box, cell histogram in LDS, exclusive scan, scatter of (x, y, z, index)
+// into the ordered copy, then one bounding box per 64-point tile.  Points of one cell land in
+// whatever order the LDS atomics resolve: the order only steers the search, never its result.
+__global__ __launch_bounds__(KS_THREADS) void p2n_knn_sort_kernel(const float *__restrict__ xyz, int N, int ntiles,
+                                                                  float4 *__restrict__ sorted, float4 *__restrict__ boxes) {
+    extern __shared__ int ks_bin[];
+    __shared__ float red[6][KS_THREADS / 64];
+    __shared__ int wtot[KS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float *P = xyz + (long)b * N * 3;
+    const float INF = __int_as_float(0x7f800000);
+    float px[KS_PPT], py[KS_PPT], pz[KS_PPT];
+    float mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
+#pragma unroll
+    for (int u = 0; u < KS_PPT; ++u) {
+        const int i = tid + u * KS_THREADS;
+        px[u] = py[u] = pz[u] = 0.f;
+        if (i < N) {
+            px[u] = P[(long)i * 3 + 0]; py[u] = P[(long)i * 3 + 1]; pz[u] = P[(long)i * 3 + 2];
+            mn[0] = fminf(mn[0], px[u]); mx[0] = fmaxf(mx[0], px[u]);
+            mn[1] = fminf(mn[1], py[u]); mx[1] = fmaxf(mx[1], py[u]);
+            mn[2] = fminf(mn[2], pz[u]); mx[2] = fmaxf(mx[2], pz[u]);
+        }
+    }
+    for (int i = tid; i < KS_BIN_WORDS; i += KS_THREADS) ks_bin[i] = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+        if (lane == 0) { red[c][wave] = mn[c]; red[3 + c][wave] = mx[c]; }
+    }
+    __syncthreads();
+    float sc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = INF, z = -INF;
+        for (int w = 0; w < KS_THREADS / 64; ++w) { a = fminf(a, red[c][w]); z = fmaxf(z, red[3 + c][w]); }
+        mn[c] = a;
+        const float ext = z - a;
+        sc[c] = (ext > 0.f && ext < INF) ? (float)((1 << KS_AXIS_BITS) - 1) / ext : 0.f;
+    }
+    int cell[KS_PPT];
+    const float top = (float)((1 << KS_AXIS_BITS) - 1);
+#pragma unroll
+    for (int u = 0; u < KS_PPT; ++u) {
+        // fmaxf/fminf drop a NaN operand: a NaN coordinate lands in cell 0
+        const unsigned cx = (unsigned)fminf(fmaxf((px[u] - mn[0]) * sc[0], 0.f), top);
+        const unsigned cy = (unsigned)fminf(fmaxf((py[u] - mn[1]) * sc[1], 0.f), top);
+        const unsigned cz = (unsigned)fminf(fmaxf((pz[u] - mn[2]) * sc[2], 0.f), top);
+        const int code = (int)(morton_spread5(cx) | (morton_spread5(cy) << 1) | (morton_spread5(cz) << 2));
+        cell[u] = code + (code >> 5);
+        if (tid + u * KS_THREADS < N) atomicAdd(&ks_bin[cell[u]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the histogram: 32 consecutive bins per thread, wave scan, wave totals
+    int mine = 0;
+    const int b0 = tid * 33;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) mine += ks_bin[b0 + j];
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const int c = ks_bin[b0 + j];
+        ks_bin[b0 + j] = base;
+        base += c;
+    }
+    __syncthreads();
+    float4 *S = sorted + (long)b * ntiles * 64;
+#pragma unroll
+    for (int u = 0; u < KS_PPT; ++u) {
+        const int i = tid + u * KS_THREADS;
+        if (i < N) {
+            const int pos = atomicAdd(&ks_bin[cell[u]], 1);
+            S[pos] = float4{px[u], py[u], pz[u], __int_as_float(i)};
+        }
+    }
+    if (N + tid < ntiles * 64) S[N + tid] = float4{0.f, 0.f, 0.f, __int_as_float(-1)};   // fewer than 64 pad entries
+    __syncthreads();   // the workgroup's stores are visible to its own loads past this point
+    for (int tile = wave; tile < ntiles; tile += KS_THREADS / 64) {
+        const float4 p = S[tile * 64 + lane];
+        const bool valid = __float_as_int(p.w) >= 0;
+        float lo[3] = {valid ? p.x : INF, valid ? p.y : INF, valid ? p.z : INF};
+        float hi[3] = {valid ? p.x : -INF, valid ? p.y : -INF, valid ? p.z : -INF};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            for (int o = 32; o > 0; o >>= 1) {
+                lo[c] = fminf(lo[c], __shfl_xor(lo[c], o));
+                hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o));
+            }
+        if (lane == 0) {
+            boxes[((long)b * ntiles + tile) * 2 + 0] = float4{lo[0], lo[1], lo[2], 0.f};
+            boxes[((long)b * ntiles + tile) * 2 + 1] = float4{hi[0], hi[1], hi[2], 0.f};
+        }
+    }
+}
+
+// The wave-resident candidate list holds one 64-bit key per lane, (distance bits << 32) | index:
+// distances are non-negative floats, so unsigned key order is (distance, index) order.
+#define KS_EMPTY 0x7f800000ffffffffull   // (inf, -1): an unfilled slot
+
+__device__ __forceinline__ unsigned long long ks_key(float d, int i) {
+    return ((unsigned long long)(unsigned)__float_as_int(d) << 32) | (unsigned)i;
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Bitonic sort of 64 keys, one per lane, ascending by lane.
+__device__ __forceinline__ unsigned long long wave_sort_u64(unsigned long long key, int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = shfl_xor_u64(key, j);
+            const bool take_min = ((lane & kk) == 0) == ((lane & j) == 0);
+            const bool oth_less = other < key;
+            key = (take_min == oth_less) ? other : key;
+        }
+    }
+    return key;
+}
+
+// One insertion of candidate key ck into the sorted list: entries behind it move one lane up.
+__device__ __forceinline__ void knn_insert_key(unsigned long long &lk, unsigned long long ck) {
+    const bool gt = lk > ck;
+    const unsigned plo = (unsigned)__float_as_int(dpp_wave_shr1(__int_as_float((int)(unsigned)lk), 0.f));
+    const unsigned phi = (unsigned)__float_as_int(dpp_wave_shr1(__int_as_float((int)(unsigned)(lk >> 32)), 0.f));
+    const unsigned long long pk = ((unsigned long long)phi << 32) | plo;   // lane 0 sees key 0: never "greater"
+    const bool pgt = pk > ck;
+    lk = gt ? (pgt ? pk : ck) : lk;
+}
+
+__global__ __launch_bounds__(KSW * 64) void p2n_knn_sorted_kernel(const float4 *__restrict__ sorted,
+                                                                  const float4 *__restrict__ boxes, int N, int ntiles, int k,
+                                                                  int32_t *__restrict__ idx, float *__restrict__ d2out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const long m0 = 2 * ((long)blockIdx.x * KSW + wave);   // position in the ordered copy
+    if (m0 >= N) return;                                    // whole wave; the kernel has no barrier
+    const bool two = m0 + 1 < N;
+    const float4 *S = sorted + (long)b * ntiles * 64;
+    const float4 *BX = boxes + (long)b * ntiles * 2;
+    const float4 q0 = S[m0], q1 = S[two ? m0 + 1 : m0];
+    const f32x2 qx = {q0.x, q1.x}, qy = {q0.y, q1.y}, qz = {q0.z, q1.z};
+    const float INF = __int_as_float(0x7f800000);
+    unsigned long long lk[2];
+    float kth[2];
+    const int own = (int)(m0 >> 6);
+
+    auto distances = [&](const float4 &p) {
+        const f32x2 dx = f32x2{p.x, p.x} - qx, dy = f32x2{p.y, p.y} - qy, dz = f32x2{p.z, p.z} - qz;
+        return (dx * dx + dy * dy) + dz * dz;
+    };
+    auto kth_of = [&](unsigned long long key) {
+        return __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), k - 1));
+    };
+    {   // the queries' own tile seeds both lists: one 64-key sort instead of ~40 serial insertions
+        const float4 p = S[(long)own * 64 + lane];
+        const int cil = __float_as_int(p.w);
+        const f32x2 dd = distances(p);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            // an infinite (overflowed) or NaN distance never enters the list, as in the streaming kernel
+            const unsigned long long key = (cil >= 0 && dd[q] < INF) ? ks_key(dd[q], cil) : KS_EMPTY;
+            lk[q] = wave_sort_u64(key, lane);
+            kth[q] = kth_of(lk[q]);
+        }
+    }
+    auto visit = [&](int t) {
+        const float4 p = S[(long)t * 64 + lane];
+        const int cil = __float_as_int(p.w);
+        const f32x2 dd = distances(p);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float d = dd[q];
+            unsigned long long mask = __ballot(cil >= 0 && d <= kth[q] && d < INF);
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
+                if (!(cd <= kth[q])) continue;             // the k-th best tightened since the ballot
+                knn_insert_key(lk[q], ks_key(cd, __builtin_amdgcn_readlane(cil, src)));
+                kth[q] = kth_of(lk[q]);
+            }
+        }
+    };
+    auto reaches = [&](float l0, float l1) { return l0 <= kth[0] || l1 <= kth[1]; };
+
+    const int own_blk = own >> 6;
+    for (int bi = 0; bi * 64 < ntiles; ++bi) {
+        // the 64-tile block that holds the queries' own tile first, then the others in order
+        const int blk = bi == 0 ? own_blk : (bi <= own_blk ? bi - 1 : bi);
+        const int t = blk * 64 + lane;
+        const bool tv = t < ntiles && t != own;
+        float lb0 = INF, lb1 = INF;
+        if (tv) {
+            const float4 lo = BX[2 * t], hi = BX[2 * t + 1];
+            f32x2 ex = f32x2{lo.x, lo.x} - qx, ey = f32x2{lo.y, lo.y} - qy, ez = f32x2{lo.z, lo.z} - qz;
+            const f32x2 fx = qx - f32x2{hi.x, hi.x}, fy = qy - f32x2{hi.y, hi.y}, fz = qz - f32x2{hi.z, hi.z};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ex[q] = fmaxf(fmaxf(ex[q], fx[q]), 0.f);
+                ey[q] = fmaxf(fmaxf(ey[q], fy[q]), 0.f);
+                ez[q] = fmaxf(fmaxf(ez[q], fz[q]), 0.f);
+            }
+            const f32x2 lb = (ex * ex + ey * ey) + ez * ez;
+            lb0 = lb[0];
+            lb1 = lb[1];
+        }
+        const unsigned long long mask = __ballot(tv && reaches(lb0, lb1));
+        // in the own block, nearest in Morton order first: alternate upwards / downwards from the own tile
+        unsigned long long up = mask, dn = 0ull;
+        if (blk == own_blk) {
+            const int ol = own & 63;
+            up = ol == 63 ? 0ull : mask & ~((2ull << ol) - 1ull);
+            dn = mask & ((1ull << ol) - 1ull);
+        }
+        bool flip = false;
+        while (up | dn) {
+            int src;
+            if (up && (!flip || !dn)) { src = __builtin_ctzll(up); up &= up - 1; }
+            else { src = 63 - __builtin_clzll(dn); dn &= ~(1ull << src); }
+            flip = !flip;
+            const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb0), src));
+            const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb1), src));
+            if (reaches(l0, l1)) visit(blk * 64 + src);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (q == 1 && !two) continue;
+        const int o = __float_as_int(q == 0 ? q0.w : q1.w);
+        if (lane < k) {
+            idx[((long)b * N + o) * k + lane] = (int)(unsigned)lk[q];
+            if (d2out) d2out[((long)b * N + o) * k + lane] = __int_as_float((int)(unsigned)(lk[q] >> 32));
+        }
+    }
+}
+
+extern "C" size_t p2n_knn_self_workspace_bytes(int B, int N) {
+    if (B < 1 || N < 1 || N > KS_MAX_N) return 256;   // larger clouds take the streaming kernel: no scratch
+    const size_t ntiles = ((size_t)N + 63) / 64;
+    return (((size_t)B * ntiles * 64 * sizeof(float4) + 255) & ~(size_t)255) + (size_t)B * ntiles * 2 * sizeof(float4) + 256;
+}
+
+extern "C" int p2n_knn_self(const float *xyz, int B, int N, int k, int32_t *idx, float *d2, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    P2N_REQUIRE(B >= 0 && N >= 1, "p2n_knn_self: bad shape B=%d N=%d", B, N);
+    P2N_REQUIRE(k >= 1 && k <= 64, "p2n_knn_self: k=%d not in [1,64]", k);
+    P2N_REQUIRE(k <= N, "p2n_knn_self: k=%d exceeds the number of points %d", k, N);
+    if (B == 0) return P2N_OK;
+    P2N_REQUIRE(xyz && idx, "p2n_knn_self: null pointer");
+    P2N_REQUIRE(B <= 65535, "p2n_knn_self: B > 65535");
+    hipStream_t s = (hipStream_t)stream;
+    if (N > KS_MAX_N) return knn_launch(xyz, xyz, B, N, N, k, idx, d2, nullptr, s);
+    const size_t need = p2n_knn_self_workspace_bytes(B, N);
+    if (!workspace || workspace_bytes < need) {
+        p2n_set_error("p2n_knn_self: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    const int ntiles = (N + 63) / 64;
+    float4 *sorted = (float4 *)workspace;
+    float4 *boxes = (float4 *)((char *)workspace + (((size_t)B * ntiles * 64 * sizeof(float4) + 255) & ~(size_t)255));
+    const size_t lds = (size_t)KS_BIN_WORDS * sizeof(int);
+    if (lds > 48 * 1024)
+        P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_knn_sort_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ps = p2n_prof_begin(P2N_K_KNN, s);
+    hipLaunchKernelGGL(p2n_knn_sort_kernel, dim3(B), dim3(KS_THREADS), lds, s, xyz, N, ntiles, sorted, boxes);
+    const unsigned blocks = (unsigned)((N + 2 * KSW - 1) / (2 * KSW));
+    hipLaunchKernelGGL(p2n_knn_sorted_kernel, dim3(blocks, B, 1), dim3(KSW * 64), 0, s, sorted, boxes, N, ntiles, k, idx, d2);
+    p2n_prof_end(ps, s);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
 extern "C" int p2n_three_nn(const float *unknown, const float *known, int B, int n, int m, float *dist2, int32_t *idx,
                             float *weight, void *stream) {
     P2N_REQUIRE(B >= 0 && n >= 0, "p2n_three_nn: bad shape B=%d n=%d", B, n);

@@ -79,6 +79,21 @@ def knn(query: torch.Tensor, ref: torch.Tensor, k: int, return_dist: bool = True
     return (idx, d2) if return_dist else idx
 
 
+def knn_self(xyz: torch.Tensor, k: int, return_dist: bool = True):
+    """xyz (B,N,3) -> the result of knn(xyz, xyz, k), searched through a Morton-ordered copy of
+    each cloud (reference losses.py:475-479 is exactly this self search)."""
+    xyz = _xyz(xyz, "xyz")
+    B, N, _ = xyz.shape
+    L = _lib.lib()
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=xyz.device)
+    d2 = torch.empty((B, N, k), dtype=torch.float32, device=xyz.device) if return_dist else None
+    ws = _rt.workspace(L.p2n_knn_self_workspace_bytes(B, max(N, 1)), xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(L.p2n_knn_self(xyz.data_ptr(), B, N, k, idx.data_ptr(), _rt.ptr(d2), ws.data_ptr(), ws.numel(),
+                                  _rt.stream_handle(xyz.device)), "p2n_knn_self")
+    return (idx, d2) if return_dist else idx
+
+
 def three_nn(unknown: torch.Tensor, known: torch.Tensor):
     """unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3), idx (B,n,3), weight (B,n,3)."""
     unknown, known = _xyz(unknown, "unknown"), _xyz(known, "known")

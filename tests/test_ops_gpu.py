@@ -183,6 +183,39 @@ def test_knn_ties_lattice():
     np.testing.assert_array_equal(gd.cpu().numpy(), wd)
 
 
+@pytest.mark.parametrize("B,N,k", [(2, 500, 21), (1, 4096, 32), (3, 8192, 17), (2, 5000, 1), (1, 64, 64), (1, 21, 21),
+                                   (2, 9001, 20), (1, 16384, 33), (1, 20000, 17), (4, 130, 64)])
+def test_knn_self_equals_streaming_search(B, N, k):
+    """The Morton-ordered self search returns what the oracle's exhaustive search returns
+    (N=20000 is beyond its LDS sort and takes the streaming kernel)."""
+    from oracle import oracle
+    from pointcloudsegmentation_amd import ops
+    xyz = _cloud(B, N, seed=N + 3 * k)
+    wi, wd = oracle.knn(xyz, xyz, k)
+    gi, gd = ops.knn_self(torch.from_numpy(xyz).cuda(), k)
+    np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(gd.cpu().numpy(), wd)
+
+
+def test_knn_self_ties_duplicates_and_clusters():
+    from oracle import oracle
+    from pointcloudsegmentation_amd import ops
+    lattice = _grid_cloud(2, 7)                                  # every distance tied many times over
+    dup = np.repeat(_cloud(1, 300, seed=5), 7, axis=1)           # every point 7 times
+    rng = np.random.default_rng(11)
+    centres = rng.random((1, 40, 3), dtype=np.float32)
+    blobs = (np.repeat(centres, 100, axis=1) + 1e-3 * rng.standard_normal((1, 4000, 3)).astype(np.float32))
+    flat = _cloud(1, 3000, seed=9)
+    flat[..., 2] = 0.25                                          # degenerate extent on one axis
+    same = np.full((1, 200, 3), 0.5, np.float32)                 # zero extent on all axes
+    for xyz, k in ((lattice, 27), (dup, 20), (blobs, 33), (flat, 17), (same, 9)):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        wi, wd = oracle.knn(xyz, xyz, k)
+        gi, gd = ops.knn_self(torch.from_numpy(xyz).cuda(), k)
+        np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+        np.testing.assert_array_equal(gd.cpu().numpy(), wd)
+
+
 def test_knn_matches_reference_neighbour_sets():
     """Against the reference's own kNN (losses.py:475-479) on a real-valued cloud:
     the 21-neighbour SETS of the exact-arithmetic cdist agree (golden knn_exact_k21)."""
@@ -206,6 +239,8 @@ def test_knn_errors():
         ops.knn(x, x, 11)        # k > N: torch.topk raises in the reference too
     with pytest.raises(ValueError):
         ops.knn(x, x, 65)
+    with pytest.raises(ValueError):
+        ops.knn_self(x, 11)
 
 
 @pytest.mark.parametrize("B,n,m", [(2, 1000, 250), (1, 4096, 1024), (2, 10, 3)])
