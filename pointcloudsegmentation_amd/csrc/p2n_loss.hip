@@ -472,6 +472,87 @@ __global__ __launch_bounds__(256) void p2n_rev_fill_kernel(const int *__restrict
     rev[off[q] + slot] = (int)(p % N);
 }
 
+// The same lists built by ONE workgroup per cloud, entirely in LDS (clouds of up to REV_MAX_N points): every
+// cloud has exactly N*(k1-1) edges, so its lists start at b*N*(k1-1) and no cross-cloud scan is needed.  In-degree
+// histogram (LDS atomics), exclusive scan (32 consecutive bins per thread, one pad word per 32 bins), offsets
+// written out, then the histogram words serve as fill cursors.  The scattered global atomics of the three-kernel
+// form above (2 per edge, ~25 G/s) become LDS atomics; global memory sees idx read twice and rev written once.
+#define REV_THREADS 1024
+#define REV_MAX_N 32768
+#define REV_WORDS (REV_MAX_N + REV_MAX_N / 32)
+__global__ __launch_bounds__(REV_THREADS) void p2n_rev_build_kernel(const int *__restrict__ idx, int B, int N, int k1,
+                                                                    int *__restrict__ off, int *__restrict__ rev) {
+    extern __shared__ int rv_bin[];
+    __shared__ int wtot[REV_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int k = k1 - 1;
+    const long gbase = (long)b * N * k;               // first list slot of this cloud
+    const int *I = idx + (long)b * N * k1;
+    const int ne = N * k1;                            // < 2^31 (checked by the caller)
+    for (int i = tid; i < REV_WORDS; i += REV_THREADS) rv_bin[i] = 0;
+    __syncthreads();
+    // edge e = p*k1 + j; column j == 0 (the point itself or a duplicate of it) is not an edge.
+    // tid = tp*k1 + tj once; the workgroup's base edge advances by REV_THREADS = sp*k1 + sj per round.
+    const int tp = tid / k1, tj = tid - tp * k1;
+    const int sp = REV_THREADS / k1, sj = REV_THREADS - sp * k1;
+    {
+        int j0 = 0, p0 = 0;                           // round base = p0*k1 + j0
+        for (int e0 = 0; e0 < ne; e0 += REV_THREADS) {
+            int j = j0 + tj, p = p0 + tp;
+            if (j >= k1) { j -= k1; ++p; }
+            const int e = e0 + tid;
+            if (e < ne && j != 0) {
+                int q = I[e];
+                if ((unsigned)q >= (unsigned)N) q = p;   // unfilled slot (-1, non-finite input): a self edge, weight 0
+                atomicAdd(&rv_bin[q + (q >> 5)], 1);
+            }
+            j0 += sj; p0 += sp;
+            if (j0 >= k1) { j0 -= k1; ++p0; }
+        }
+    }
+    __syncthreads();
+    int mine = 0;
+    const int b0 = tid * 33;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) mine += rv_bin[b0 + j];
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const int c = rv_bin[b0 + j];
+        rv_bin[b0 + j] = base;
+        base += c;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += REV_THREADS) off[(long)b * N + i] = (int)(gbase + rv_bin[i + (i >> 5)]);
+    if (b == B - 1 && tid == 0) off[(long)B * N] = (int)((long)B * N * k);
+    __syncthreads();
+    {
+        int j0 = 0, p0 = 0;                           // round base = p0*k1 + j0
+        for (int e0 = 0; e0 < ne; e0 += REV_THREADS) {
+            int j = j0 + tj, p = p0 + tp;
+            if (j >= k1) { j -= k1; ++p; }
+            const int e = e0 + tid;
+            if (e < ne && j != 0) {
+                int q = I[e];
+                if ((unsigned)q >= (unsigned)N) q = p;
+                const int slot = atomicAdd(&rv_bin[q + (q >> 5)], 1);
+                rev[gbase + slot] = p;
+            }
+            j0 += sj; p0 += sp;
+            if (j0 >= k1) { j0 -= k1; ++p0; }
+        }
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__restrict__ en, const int *__restrict__ idx,
                                                              const int *__restrict__ off, const int *__restrict__ rev,
@@ -695,6 +776,12 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     if (E <= 256 && k1 <= 64 && P * (long)k1 < 0x7fffffffL) {
         // reverse neighbour lists, then a pull per point (no float atomics)
         const long ne = P * (long)k1, nb = (P + 1 + 1023) / 1024;
+        if (N <= REV_MAX_N && (long)N * k1 < 0x7fffffffL) {
+            const size_t lds = sizeof(int) * REV_WORDS;
+            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_rev_build_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(p2n_rev_build_kernel, dim3(B), dim3(REV_THREADS), lds, s, w.idx, B, N, k1, w.off, w.rev);
+        } else {
         P2N_CHECK_HIP(hipMemsetAsync(w.deg, 0, sizeof(int) * (P + 4), s));
         hipLaunchKernelGGL(p2n_rev_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, w.idx, P, N, k1, w.deg);
         hipLaunchKernelGGL(p2n_scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, s, w.deg, P + 1, w.off, w.totals);
@@ -702,6 +789,7 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
         hipLaunchKernelGGL(p2n_scan_add_kernel, dim3((unsigned)nb), dim3(256), 0, s, w.off, P + 1, w.totals);
         hipLaunchKernelGGL(p2n_rev_fill_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, w.idx, P, N, k1, w.off, w.deg,
                            w.rev);
+        }
         const int V = (E + 63) / 64;
         if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
         else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);

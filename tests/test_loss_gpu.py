@@ -40,7 +40,8 @@ def test_loss_matches_reference_golden():
 @pytest.mark.parametrize("B,N,E,ninst", [(2, 500, 64, 7), (3, 1000, 32, 33), (1, 2048, 64, 2), (2, 300, 100, 5),
                                          (2, 1500, 256, 80),   # more instance rows than the LDS copy holds: global-atomic path
                                          (1, 700, 20, 9),      # channel count that is no multiple of 16
-                                         (2, 1030, 200, 3)])   # four channels per lane, chunk tail
+                                         (2, 1030, 200, 3),    # four channels per lane, chunk tail
+                                         (1, 33000, 8, 4)])    # beyond the per-cloud LDS paths: streaming kNN, three-kernel list build
 def test_loss_matches_oracle(B, N, E, ninst):
     from oracle import loss_oracle
     from pointcloudsegmentation_amd.synth import make_batch, make_labels

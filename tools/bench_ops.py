@@ -98,6 +98,18 @@ if not a.no_lidar:
     lvl["knn_k32_16k_queries"] = entry(ms, 12 * 1_000_000 + 12 * 16384 + 4 * 16384 * 32, "VALU-bound: 1.6e10 distance tests")
     lvl["knn_k32_16k_queries"]["G_distance_tests_per_s"] = 16384 * 1e6 / (ms * 1e-3) / 1e9
     out["levels"]["lidar_1m"] = lvl
+if not a.only_gather:
+    # the smoothness loss's neighbour search at the training shape: streaming kNN beside the Morton-ordered self search
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cl = torch.rand(32, 8192, 3, device="cuda", generator=g)
+    lvl = {}
+    nbytes = 32 * (12 * 8192 + 4 * 8192 * 17)
+    ms, i0 = timed(lambda: ops.knn(cl, cl, 17, return_dist=False), 10)
+    lvl["knn_streaming_k17"] = entry(ms, nbytes, "xyz read, 4*N*k indices written (VALU-bound: N*N distance tests)")
+    ms, i1 = timed(lambda: ops.knn_self(cl, 17, return_dist=False), 10)
+    lvl["knn_self_k17"] = entry(ms, nbytes, "same result through the Morton-ordered copy (sort + pruned search)")
+    lvl["knn_self_k17"]["identical_to_streaming"] = bool((i0 == i1).all())
+    out["levels"]["loss_32x8192"] = lvl
 if a.only_gather:
     print(json.dumps({lv: {k: round(v["GB_per_s"]) for k, v in d.items() if k in ("group_gather", "three_interpolate")}
                       for lv, d in out["levels"].items()}))
