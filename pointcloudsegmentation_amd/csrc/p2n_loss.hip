@@ -472,50 +472,70 @@ __global__ __launch_bounds__(256) void p2n_rev_fill_kernel(const int *__restrict
     rev[off[q] + slot] = (int)(p % N);
 }
 
-// The same lists built by ONE workgroup per cloud, entirely in LDS (clouds of up to REV_MAX_N points): every
-// cloud has exactly N*(k1-1) edges, so its lists start at b*N*(k1-1) and no cross-cloud scan is needed.  In-degree
-// histogram (LDS atomics), exclusive scan (32 consecutive bins per thread, one pad word per 32 bins), offsets
-// written out, then the histogram words serve as fill cursors.  The scattered global atomics of the three-kernel
-// form above (2 per edge, ~25 G/s) become LDS atomics; global memory sees idx read twice and rev written once.
+// The same lists built with the histogram in LDS (clouds of up to REV_MAX_N points).  Every cloud has exactly
+// N*(k1-1) edges, so its lists start at b*N*(k1-1) and no cross-cloud scan is needed.  A cloud's targets are cut
+// into H slices, one workgroup each: the workgroup reads ALL edges of the cloud (coalesced, L2-resident), counts
+// those that point into its slice in LDS and, in passing, how many point below it (= where its lists start),
+// scans, writes the offsets, and uses the histogram words as fill cursors.  The scattered global atomics of the
+// three-kernel form above (2 per edge, ~25 G/s) become LDS atomics; what is left scattered is one 4-byte store
+// per edge, spread over B*H compute units (one CU retires only ~1 scattered store per 2 clocks).
 #define REV_THREADS 1024
 #define REV_MAX_N 32768
+#define REV_U 8
 #define REV_WORDS (REV_MAX_N + REV_MAX_N / 32)
 __global__ __launch_bounds__(REV_THREADS) void p2n_rev_build_kernel(const int *__restrict__ idx, int B, int N, int k1,
-                                                                    int *__restrict__ off, int *__restrict__ rev) {
+                                                                    int slice, int *__restrict__ off,
+                                                                    int *__restrict__ rev) {
     extern __shared__ int rv_bin[];
-    __shared__ int wtot[REV_THREADS / 64];
+    __shared__ int wtot[REV_THREADS / 64], wbelow[REV_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
+    const int lo = blockIdx.x * slice, hi = min(N, lo + slice);   // this workgroup's targets
     const int k = k1 - 1;
     const long gbase = (long)b * N * k;               // first list slot of this cloud
     const int *I = idx + (long)b * N * k1;
     const int ne = N * k1;                            // < 2^31 (checked by the caller)
-    for (int i = tid; i < REV_WORDS; i += REV_THREADS) rv_bin[i] = 0;
+    const int words = slice + (slice >> 5);
+    for (int i = tid; i < words; i += REV_THREADS) rv_bin[i] = 0;
     __syncthreads();
     // edge e = p*k1 + j; column j == 0 (the point itself or a duplicate of it) is not an edge.
     // tid = tp*k1 + tj once; the workgroup's base edge advances by REV_THREADS = sp*k1 + sj per round.
     const int tp = tid / k1, tj = tid - tp * k1;
     const int sp = REV_THREADS / k1, sj = REV_THREADS - sp * k1;
+    int below = 0;
     {
+        // REV_U rounds of loads in flight per step: one load per round would leave the pass latency-bound
         int j0 = 0, p0 = 0;                           // round base = p0*k1 + j0
-        for (int e0 = 0; e0 < ne; e0 += REV_THREADS) {
-            int j = j0 + tj, p = p0 + tp;
-            if (j >= k1) { j -= k1; ++p; }
-            const int e = e0 + tid;
-            if (e < ne && j != 0) {
-                int q = I[e];
-                if ((unsigned)q >= (unsigned)N) q = p;   // unfilled slot (-1, non-finite input): a self edge, weight 0
-                atomicAdd(&rv_bin[q + (q >> 5)], 1);
+        for (int e0 = 0; e0 < ne; e0 += REV_U * REV_THREADS) {
+            int qv[REV_U];
+#pragma unroll
+            for (int u = 0; u < REV_U; ++u) {
+                const int e = e0 + u * REV_THREADS + tid;
+                qv[u] = e < ne ? I[e] : 0;
             }
-            j0 += sj; p0 += sp;
-            if (j0 >= k1) { j0 -= k1; ++p0; }
+#pragma unroll
+            for (int u = 0; u < REV_U; ++u) {
+                int j = j0 + tj, p = p0 + tp;
+                if (j >= k1) { j -= k1; ++p; }
+                if (e0 + u * REV_THREADS + tid < ne && j != 0) {
+                    int q = qv[u];
+                    if ((unsigned)q >= (unsigned)N) q = p;   // unfilled slot (-1, non-finite input): a self edge, weight 0
+                    if (q < lo) ++below;
+                    else if (q < hi) atomicAdd(&rv_bin[(q - lo) + ((q - lo) >> 5)], 1);
+                }
+                j0 += sj; p0 += sp;
+                if (j0 >= k1) { j0 -= k1; ++p0; }
+            }
         }
     }
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+    if (lane == 0) wbelow[wave] = below;
     __syncthreads();
+    // exclusive scan of the slice's histogram: `per` consecutive bins per thread (per <= 32), wave scan, wave totals
+    const int per = slice / REV_THREADS;              // slice is a multiple of REV_THREADS (see the launch)
     int mine = 0;
-    const int b0 = tid * 33;
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) mine += rv_bin[b0 + j];
+    const int i0 = tid * per;
+    for (int j = 0; j < per; ++j) mine += rv_bin[(i0 + j) + ((i0 + j) >> 5)];
     int incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const int up = __shfl_up(incl, o);
@@ -524,31 +544,44 @@ __global__ __launch_bounds__(REV_THREADS) void p2n_rev_build_kernel(const int *_
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     int base = incl - mine;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) {
-        const int c = rv_bin[b0 + j];
-        rv_bin[b0 + j] = base;
+    for (int w = 0; w < REV_THREADS / 64; ++w) {
+        base += wbelow[w];
+        if (w < wave) base += wtot[w];
+    }
+    for (int j = 0; j < per; ++j) {
+        const int w = (i0 + j) + ((i0 + j) >> 5);
+        const int c = rv_bin[w];
+        rv_bin[w] = base;
         base += c;
     }
     __syncthreads();
-    for (int i = tid; i < N; i += REV_THREADS) off[(long)b * N + i] = (int)(gbase + rv_bin[i + (i >> 5)]);
-    if (b == B - 1 && tid == 0) off[(long)B * N] = (int)((long)B * N * k);
+    for (int i = lo + tid; i < hi; i += REV_THREADS) off[(long)b * N + i] = (int)(gbase + rv_bin[(i - lo) + ((i - lo) >> 5)]);
+    if (b == B - 1 && blockIdx.x == 0 && tid == 0) off[(long)B * N] = (int)((long)B * N * k);
     __syncthreads();
     {
-        int j0 = 0, p0 = 0;                           // round base = p0*k1 + j0
-        for (int e0 = 0; e0 < ne; e0 += REV_THREADS) {
-            int j = j0 + tj, p = p0 + tp;
-            if (j >= k1) { j -= k1; ++p; }
-            const int e = e0 + tid;
-            if (e < ne && j != 0) {
-                int q = I[e];
-                if ((unsigned)q >= (unsigned)N) q = p;
-                const int slot = atomicAdd(&rv_bin[q + (q >> 5)], 1);
-                rev[gbase + slot] = p;
+        int j0 = 0, p0 = 0;
+        for (int e0 = 0; e0 < ne; e0 += REV_U * REV_THREADS) {
+            int qv[REV_U];
+#pragma unroll
+            for (int u = 0; u < REV_U; ++u) {
+                const int e = e0 + u * REV_THREADS + tid;
+                qv[u] = e < ne ? I[e] : 0;
             }
-            j0 += sj; p0 += sp;
-            if (j0 >= k1) { j0 -= k1; ++p0; }
+#pragma unroll
+            for (int u = 0; u < REV_U; ++u) {
+                int j = j0 + tj, p = p0 + tp;
+                if (j >= k1) { j -= k1; ++p; }
+                if (e0 + u * REV_THREADS + tid < ne && j != 0) {
+                    int q = qv[u];
+                    if ((unsigned)q >= (unsigned)N) q = p;
+                    if (q >= lo && q < hi) {
+                        const int slot = atomicAdd(&rv_bin[(q - lo) + ((q - lo) >> 5)], 1);
+                        rev[gbase + slot] = p;
+                    }
+                }
+                j0 += sj; p0 += sp;
+                if (j0 >= k1) { j0 -= k1; ++p0; }
+            }
         }
     }
 }
@@ -777,10 +810,17 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
         // reverse neighbour lists, then a pull per point (no float atomics)
         const long ne = P * (long)k1, nb = (P + 1 + 1023) / 1024;
         if (N <= REV_MAX_N && (long)N * k1 < 0x7fffffffL) {
-            const size_t lds = sizeof(int) * REV_WORDS;
-            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_rev_build_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(p2n_rev_build_kernel, dim3(B), dim3(REV_THREADS), lds, s, w.idx, B, N, k1, w.off, w.rev);
+            // H slices of the cloud's targets, one workgroup each: enough workgroups for the chip, slices a
+            // multiple of the workgroup size (the scan gives every thread the same number of bins)
+            int H = 256 / B;
+            H = H < 1 ? 1 : (H > 16 ? 16 : H);
+            int slice = ((N + H - 1) / H + REV_THREADS - 1) / REV_THREADS * REV_THREADS;
+            H = (N + slice - 1) / slice;
+            const size_t lds = sizeof(int) * (size_t)(slice + slice / 32);
+            if (lds > 48 * 1024)
+                P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_rev_build_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(p2n_rev_build_kernel, dim3(H, B), dim3(REV_THREADS), lds, s, w.idx, B, N, k1, slice, w.off, w.rev);
         } else {
         P2N_CHECK_HIP(hipMemsetAsync(w.deg, 0, sizeof(int) * (P + 4), s));
         hipLaunchKernelGGL(p2n_rev_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, w.idx, P, N, k1, w.deg);
