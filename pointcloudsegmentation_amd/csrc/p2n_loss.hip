@@ -615,14 +615,19 @@ template <int V>
 __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__restrict__ en, const int *__restrict__ idx,
                                                              const int *__restrict__ off, const int *__restrict__ rev,
                                                              long P, int N, int E, int k1, float w,
-                                                             float *__restrict__ den) {
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                             float *__restrict__ den, float *__restrict__ part) {
+    // part != NULL: the forward value rides along -- the distances of the point's own k edges are summed per
+    // workgroup into part[blockIdx.x], exactly what p2n_smooth_vec_kernel<V,false> would have written
+    __shared__ float sh[4];
+    const long p_ = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
-    if (p >= P) return;   // whole wave
+    const bool live = p_ < P;
+    const long p = live ? p_ : 0;
     const long base = (p / N) * (long)N;
     const int myidx = lane < k1 ? idx[p * k1 + lane] : 0;
-    const int r0 = off[p], nrev = off[p + 1] - r0;
-    const int k = k1 - 1, total = k + nrev;
+    const int r0 = off[p], nrev = live ? off[p + 1] - r0 : 0;
+    const int k = k1 - 1, total = live ? k + nrev : 0;
+    float dsum = 0.f;
     float ep[V][4], acc[V][4];
 #pragma unroll
     for (int v = 0; v < V; ++v)
@@ -666,6 +671,7 @@ __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__res
                     }
                 s = row16_sum(s);
                 const float d = sqrtf(s);
+                dsum += (ok[u] && l == 0 && t0 + u0 + 4 * u + g < k) ? d : 0.f;   // own edges only: each counted once
                 const float r = (ok[u] && d > 0.f) ? w / d : 0.f;
 #pragma unroll
                 for (int v = 0; v < V; ++v)
@@ -682,8 +688,12 @@ __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__res
             t += __shfl_xor(t, 16);
             t += __shfl_xor(t, 32);
             const int c = 64 * v + 16 * e + l;
-            if (g == 0 && c < E) den[p * E + c] = t;
+            if (live && g == 0 && c < E) den[p * E + c] = t;
         }
+    if (part) {
+        dsum = block_sum(dsum, sh);
+        if (threadIdx.x == 0) part[blockIdx.x] = dsum;
+    }
 }
 
 static void smooth_launch(bool bwd, const float *en, const int *idx, long P, int N, int E, int k1, float w, float *part,
@@ -817,12 +827,15 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     // smoothness: exact kNN of every point within its own cloud (k+1 incl. the point itself)
     int rc = p2n_knn_self(points, B, N, k1, w.idx, nullptr, w.knn_ws, w.knn_bytes, stream_);
     if (rc) return rc;
-    smooth_launch(false, w.en, w.idx, P, N, E, k1, 0.f, w.spart, nullptr, (unsigned)pb, s);
-    P2N_CHECK_HIP(hipGetLastError());
     const float smooth_scale = 1.0f / ((float)N * (float)k) / (float)B;
-    hipLaunchKernelGGL(p2n_loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.pull_b, w.push_b, B, w.spart, (long)pb,
-                       smooth_scale, losses);
-    P2N_CHECK_HIP(hipGetLastError());
+    const bool fused = P * (long)k1 < 0x7fffffffL;   // reverse-list backward; it also produces the forward partial sums
+    if (!want || !fused) {
+        smooth_launch(false, w.en, w.idx, P, N, E, k1, 0.f, w.spart, nullptr, (unsigned)pb, s);
+        P2N_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(p2n_loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.pull_b, w.push_b, B, w.spart, (long)pb,
+                           smooth_scale, losses);
+        P2N_CHECK_HIP(hipGetLastError());
+    }
     if (!want) return P2N_OK;
     // gradients w.r.t. the normalised embeddings, then back through the normalisation
     hipLaunchKernelGGL(p2n_pull_b_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, cnt, w.mu, w.G, w.dmu, w.coef, P, N, E,
@@ -831,7 +844,7 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, demb_pull, w.en, w.rn, P, E, demb_pull);
     hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, demb_push, w.en, w.rn, P, E, demb_push);
     P2N_CHECK_HIP(hipGetLastError());
-    if (E <= 256 && k1 <= 64 && P * (long)k1 < 0x7fffffffL) {
+    if (fused) {
         // reverse neighbour lists, then a pull per point (no float atomics)
         const long ne = P * (long)k1, nb = (P + 1 + 1023) / 1024;
         if (N <= REV_MAX_N && (long)N * k1 < 0x7fffffffL) {
@@ -856,10 +869,12 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
                            w.rev);
         }
         const int V = (E + 63) / 64;
-        if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
-        else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
-        else if (V == 3) hipLaunchKernelGGL(p2n_smooth_pull_kernel<3>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
-        else hipLaunchKernelGGL(p2n_smooth_pull_kernel<4>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den);
+        if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
+        else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
+        else if (V == 3) hipLaunchKernelGGL(p2n_smooth_pull_kernel<3>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
+        else hipLaunchKernelGGL(p2n_smooth_pull_kernel<4>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
+        hipLaunchKernelGGL(p2n_loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.pull_b, w.push_b, B, w.spart, (long)pb,
+                           smooth_scale, losses);
     } else {
         P2N_CHECK_HIP(hipMemsetAsync(w.den, 0, sizeof(float) * P * E, s));
         smooth_launch(true, w.en, w.idx, P, N, E, k1, smooth_scale, nullptr, w.den, (unsigned)pb, s);
