@@ -282,8 +282,10 @@ __global__ __launch_bounds__(256) void p2n_pull_b_kernel(const float *__restrict
                                                         const int *__restrict__ bg, const int *__restrict__ cnt,
                                                         const float *__restrict__ mu, const float *__restrict__ G,
                                                         const float *__restrict__ dmu, const float *__restrict__ coef,
-                                                        long P, int N, int E, float delta_v,
+                                                        const float *__restrict__ rn, long P, int N, int E, float delta_v,
                                                         float *__restrict__ dpull, float *__restrict__ dpush) {
+    // gradients w.r.t. the normalised embedding, taken straight back through en = e / |e| (what
+    // p2n_normalize_bwd_kernel does for a stored gradient): out = (g - en * <en, g>) * rn
     const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
@@ -292,18 +294,47 @@ __global__ __launch_bounds__(256) void p2n_pull_b_kernel(const float *__restrict
         for (int c = lane; c < E; c += 64) { dpull[p * E + c] = 0.f; dpush[p * E + c] = 0.f; }
         return;
     }
+    float ev[4], dv[4];   // E <= 256: up to four channels per lane
     float s = 0.f;
-    for (int c = lane; c < E; c += 64) { const float d = en[p * E + c] - mu[(long)i * E + c]; s = fmaf(d, d, s); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        ev[q] = dv[q] = 0.f;
+        if (c < E) {
+            ev[q] = en[p * E + c];
+            dv[q] = ev[q] - mu[(long)i * E + c];
+            s = fmaf(dv[q], dv[q], s);
+        }
+    }
     s = wave_sum(s);
     const float dist = sqrtf(s);
     const bool act = (dist - delta_v > 0.f) && dist > 0.f;
     const float r = act ? 1.0f / dist : 0.f;
     const float rn_i = 1.0f / (float)cnt[i];
     const float cb = coef[p / N] * rn_i;
-    for (int c = lane; c < E; c += 64) {
-        const float u = (en[p * E + c] - mu[(long)i * E + c]) * r;
-        dpull[p * E + c] = cb * (u - G[(long)i * E + c] * rn_i);
-        dpush[p * E + c] = dmu[(long)i * E + c] * rn_i;
+    float gp[4], gs[4], sp = 0.f, ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        gp[q] = gs[q] = 0.f;
+        if (c < E) {
+            const float u = dv[q] * r;
+            gp[q] = cb * (u - G[(long)i * E + c] * rn_i);
+            gs[q] = dmu[(long)i * E + c] * rn_i;
+            sp = fmaf(ev[q], gp[q], sp);
+            ss = fmaf(ev[q], gs[q], ss);
+        }
+    }
+    sp = wave_sum(sp);
+    ss = wave_sum(ss);
+    const float rp = rn[p];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        if (c < E) {
+            dpull[p * E + c] = (gp[q] - ev[q] * sp) * rp;
+            dpush[p * E + c] = (gs[q] - ev[q] * ss) * rp;
+        }
     }
 }
 
@@ -614,8 +645,8 @@ __global__ __launch_bounds__(REV_THREADS) void p2n_rev_build_kernel(const int *_
 template <int V>
 __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__restrict__ en, const int *__restrict__ idx,
                                                              const int *__restrict__ off, const int *__restrict__ rev,
-                                                             long P, int N, int E, int k1, float w,
-                                                             float *__restrict__ den, float *__restrict__ part) {
+                                                             const float *__restrict__ rn, long P, int N, int E, int k1,
+                                                             float w, float *__restrict__ out, float *__restrict__ part) {
     // part != NULL: the forward value rides along -- the distances of the point's own k edges are summed per
     // workgroup into part[blockIdx.x], exactly what p2n_smooth_vec_kernel<V,false> would have written
     __shared__ float sh[4];
@@ -680,6 +711,9 @@ __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__res
             }
         }
     }
+    // den[p] (sum of the four rows' shares), taken straight back through en = e / |e|:
+    // out = (den - en * <en, den>) * rn, the point's own row is still in registers
+    float dot = 0.f;
 #pragma unroll
     for (int v = 0; v < V; ++v)
 #pragma unroll
@@ -687,8 +721,17 @@ __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__res
             float t = acc[v][e];
             t += __shfl_xor(t, 16);
             t += __shfl_xor(t, 32);
+            acc[v][e] = t;
+            dot = fmaf(ep[v][e], t, dot);   // ep is zero beyond channel E
+        }
+    dot = row16_sum(dot);
+    const float rp = rn[p];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
             const int c = 64 * v + 16 * e + l;
-            if (live && g == 0 && c < E) den[p * E + c] = t;
+            if (live && g == 0 && c < E) out[p * E + c] = (acc[v][e] - ep[v][e] * dot) * rp;
         }
     if (part) {
         dsum = block_sum(dsum, sh);
@@ -838,11 +881,8 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     }
     if (!want) return P2N_OK;
     // gradients w.r.t. the normalised embeddings, then back through the normalisation
-    hipLaunchKernelGGL(p2n_pull_b_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, cnt, w.mu, w.G, w.dmu, w.coef, P, N, E,
-                       delta_v, demb_pull, demb_push);   // staged in the outputs, normalised in place below
-    P2N_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, demb_pull, w.en, w.rn, P, E, demb_pull);
-    hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, demb_push, w.en, w.rn, P, E, demb_push);
+    hipLaunchKernelGGL(p2n_pull_b_kernel, dim3(pb), dim3(256), 0, s, w.en, inst, bg, cnt, w.mu, w.G, w.dmu, w.coef, w.rn, P, N,
+                       E, delta_v, demb_pull, demb_push);
     P2N_CHECK_HIP(hipGetLastError());
     if (fused) {
         // reverse neighbour lists, then a pull per point (no float atomics)
@@ -869,18 +909,17 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
                            w.rev);
         }
         const int V = (E + 63) / 64;
-        if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
-        else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
-        else if (V == 3) hipLaunchKernelGGL(p2n_smooth_pull_kernel<3>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
-        else hipLaunchKernelGGL(p2n_smooth_pull_kernel<4>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, P, N, E, k1, smooth_scale, w.den, w.spart);
+        if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
+        else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
+        else if (V == 3) hipLaunchKernelGGL(p2n_smooth_pull_kernel<3>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
+        else hipLaunchKernelGGL(p2n_smooth_pull_kernel<4>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
         hipLaunchKernelGGL(p2n_loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.pull_b, w.push_b, B, w.spart, (long)pb,
                            smooth_scale, losses);
     } else {
         P2N_CHECK_HIP(hipMemsetAsync(w.den, 0, sizeof(float) * P * E, s));
         smooth_launch(true, w.en, w.idx, P, N, E, k1, smooth_scale, nullptr, w.den, (unsigned)pb, s);
+        hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, w.den, w.en, w.rn, P, E, demb_smooth);
     }
-    P2N_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, w.den, w.en, w.rn, P, E, demb_smooth);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
