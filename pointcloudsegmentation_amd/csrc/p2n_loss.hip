@@ -7,7 +7,7 @@
 // cloud) and materialises an N x N distance matrix per cloud (268 MB at N = 8192).
 // Here: instances arrive as dense ids (one integer per point), per-instance sums are
 // segmented atomics, the per-cloud I x I push term runs in one workgroup, and the
-// neighbour search is p2n_knn (never N x N).  All float arithmetic is fp32.
+// neighbour search is p2n_knn_self (never N x N).  All float arithmetic is fp32.
 //
 // Inputs prepared by the host (integer plumbing only, see losses.py): inst[P] = dense id
 // of (cloud, label) in ascending (cloud, label) order, cnt[T] points per id, bg[T] = 1
