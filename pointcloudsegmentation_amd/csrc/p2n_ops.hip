@@ -205,10 +205,17 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
                     bool ready = true;
                     if (lane < A.G) {
                         const u64 *sl = slot + lane * 4;
-                        v0 = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v1 = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v2 = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v3 = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // two 16-byte sc1 loads (L1 bypassed, as the agent-scope atomic loads they replace) instead of
+                        // four 8-byte ones: half the requests in the polling CU's memory queue.  Every 8-byte granule
+                        // carries its own tag, so it does not matter which of the two halves of a load is newer.
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 a, c;
+                        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                                     "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(a), "=&v"(c) : "v"(sl) : "memory");
+                        v0 = ((u64)a[1] << 32) | a[0]; v1 = ((u64)a[3] << 32) | a[2];
+                        v2 = ((u64)c[1] << 32) | c[0]; v3 = ((u64)c[3] << 32) | c[2];
                         ready = v0 != 0ull && (v1 >> 32) != 0ull && (v2 >> 32) != 0ull && (v3 >> 32) != 0ull;
                     }
                     ok = __all(ready);
