@@ -87,7 +87,11 @@ int p2n_forward_eval_bf16(const float *x, int B, int N, int feature_dim, int emb
  * p2n_train_backward (reference train.py:131, loss.backward()) consumes the same,
  * untouched workspace plus gemb = dL/d emb (B,N,E) and overwrites the 34 gradient
  * tensors grads_host points at, in the order (W, bias, [bn.weight, bn.bias]) per layer.
- * Weight gradients are summed with fp32 atomics (order not reproducible). */
+ * Weight gradients are summed with fp32 atomics (order not reproducible).
+ * momentum < 0 selects eval-mode BatchNorm for a differentiable forward (model.eval()
+ * with autograd enabled, e.g. fine-tuning with frozen statistics): the layers normalise
+ * with running_mean/var, which stay untouched, and the backward on that workspace uses
+ * dz = gamma*rstd*dy (convolution biases then keep a non-zero gradient). */
 size_t p2n_train_workspace_bytes(int B, int N, int feature_dim, int embedding_dim);
 int p2n_train_forward(const float *x, int B, int N, int feature_dim, int embedding_dim,
                       const void *const *params_host, float momentum, float *emb, float *global_f,

@@ -487,11 +487,29 @@ __global__ void p2n_bn_finalize_fwd_kernel(const float *__restrict__ part, const
     }
 }
 
-// backward finalize: dgamma, dbeta and the loader constants {s,t,A1,A2,A3}
+// eval-mode BatchNorm (running statistics, nothing updated): the same table from the stored statistics
+__global__ void p2n_bn_eval_tab_kernel(int rows, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                       const float *__restrict__ run_mean, const float *__restrict__ run_var,
+                                       float *__restrict__ tab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= rows) return;
+    const double mean = run_mean[c];
+    const double rstd = 1.0 / sqrt((double)run_var[c] + BN_EPS);
+    const double sc = (double)gamma[c] * rstd;
+    tab[c] = (float)sc;
+    tab[rows + c] = (float)((double)beta[c] - mean * sc);
+    tab[2 * rows + c] = (float)mean;
+    tab[3 * rows + c] = (float)rstd;
+}
+
+// backward finalize: dgamma, dbeta and the loader constants {s,t,A1,A2,A3}.  With running statistics
+// (*mode != 0) the statistics do not depend on the batch: dz = s*dy (A2 = A3 = 0) and the bias of the
+// convolution in front keeps a gradient, db = s * sum dy.
 __global__ void p2n_bn_finalize_bwd_kernel(const float *__restrict__ part, int rows, int S, int P,
                                            const float *__restrict__ gamma, const float *__restrict__ ftab,
                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                           float *__restrict__ btab) {
+                                           float *__restrict__ btab, const int *__restrict__ mode,
+                                           float *__restrict__ db) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= rows) return;
     double sdy = 0, sdyz = 0;
@@ -502,9 +520,11 @@ __global__ void p2n_bn_finalize_bwd_kernel(const float *__restrict__ part, int r
     const double m1 = sdy / P, m2 = sdyz / P;
     btab[c] = ftab[c];
     btab[rows + c] = ftab[rows + c];
-    btab[2 * rows + c] = (float)(g * rstd);                                     // A1
-    btab[3 * rows + c] = (float)(-g * rstd * m1 + g * rstd * rstd * mean * m2); // A2
-    btab[4 * rows + c] = (float)(-g * rstd * rstd * m2);                        // A3
+    const bool ev = *mode != 0;
+    btab[2 * rows + c] = (float)(g * rstd);                                                  // A1
+    btab[3 * rows + c] = ev ? 0.f : (float)(-g * rstd * m1 + g * rstd * rstd * mean * m2);  // A2
+    btab[4 * rows + c] = ev ? 0.f : (float)(-g * rstd * rstd * m2);                         // A3
+    if (ev) db[c] = (float)(g * rstd * sdy);
 }
 
 // ---------------------------------------------------------------- global max branch
@@ -615,6 +635,7 @@ struct Net {
     float *z[8];          // pre-BN conv outputs, (cout, Ppad)
     float *ftab[8];       // {s,t,mean,rstd}[cout]
     float *btab;          // {s,t,A1,A2,A3}[256] scratch
+    int *mode;
     float *part;          // partial sums
     float *wimg;          // weight image scratch (256*256)
     float *g, *bias6c, *dzsum6, *dg;   // [B][256]
@@ -640,6 +661,7 @@ size_t carve(Net &n, char *base) {
     n.arg = (int *)take(sizeof(int) * (size_t)n.B * 256);
     n.da[0] = (float *)take(sizeof(float) * 256 * (size_t)n.Ppad);
     n.da[1] = (float *)take(sizeof(float) * 256 * (size_t)n.Ppad);
+    n.mode = (int *)take(sizeof(int));   // non-zero: the forward normalised with the running statistics (eval-mode BatchNorm)
     return off;
 }
 
@@ -744,6 +766,8 @@ static int check_common(const char *fn, int B, int N, int F, int E) {
 
 // Train-mode forward.  params_host: HOST array of 50 DEVICE pointers in flat order
 // (W,b,[gamma,beta,running_mean,running_var]) x layers; running stats are updated in place.
+// momentum < 0: eval-mode BatchNorm for a differentiable forward -- the layers normalise with the
+// running statistics, which stay untouched; p2n_train_backward on the same workspace follows suit.
 extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, const void *const *params_host,
                                  float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
                                  void *workspace, size_t workspace_bytes, void *stream_) {
@@ -760,6 +784,8 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
     carve(n, (char *)workspace);
     bind_params(n, params_host);
     hipStream_t s = (hipStream_t)stream_;
+    const bool eval_stats = momentum < 0.f;   // eval-mode BatchNorm: running statistics, not updated
+    P2N_CHECK_HIP(hipMemsetAsync(n.mode, eval_stats ? 1 : 0, sizeof(int), s));   // the backward reads it on the device
     for (int l = 0; l < 9; ++l) {
         const int K = (l == 6) ? 256 : n.cin[l];
         TRY(pack_w(n.W[l], n.cin[l], 0, n.cout[l], K, 0, n.wimg, s));
@@ -774,12 +800,17 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
             else { a.out = n.z[l]; TRY((launch_layer<LD_BNRELU, false>(a, s))); }
         }
         if (l == 8) break;
-        StatArgs st = {};
-        st.z = n.z[l]; st.part = n.part; st.rows = n.cout[l]; st.P = n.P; st.Ppad = n.Ppad; st.S = STAT_S; st.N = N;
-        hipLaunchKernelGGL(p2n_row_stats_kernel<ST_FWD>, dim3(n.cout[l], STAT_S), dim3(256), 0, s, st);
-        P2N_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(p2n_bn_finalize_fwd_kernel, dim3((n.cout[l] + 63) / 64), dim3(64), 0, s, n.part, n.z[l], n.Ppad,
-                           n.cout[l], STAT_S, n.P, n.gamma[l], n.beta[l], n.rmean[l], n.rvar[l], momentum, n.ftab[l]);
+        if (eval_stats) {
+            hipLaunchKernelGGL(p2n_bn_eval_tab_kernel, dim3((n.cout[l] + 63) / 64), dim3(64), 0, s, n.cout[l], n.gamma[l],
+                               n.beta[l], n.rmean[l], n.rvar[l], n.ftab[l]);
+        } else {
+            StatArgs st = {};
+            st.z = n.z[l]; st.part = n.part; st.rows = n.cout[l]; st.P = n.P; st.Ppad = n.Ppad; st.S = STAT_S; st.N = N;
+            hipLaunchKernelGGL(p2n_row_stats_kernel<ST_FWD>, dim3(n.cout[l], STAT_S), dim3(256), 0, s, st);
+            P2N_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(p2n_bn_finalize_fwd_kernel, dim3((n.cout[l] + 63) / 64), dim3(64), 0, s, n.part, n.z[l], n.Ppad,
+                               n.cout[l], STAT_S, n.P, n.gamma[l], n.beta[l], n.rmean[l], n.rvar[l], momentum, n.ftab[l]);
+        }
         P2N_CHECK_HIP(hipGetLastError());
         if (l == 5) {
             hipLaunchKernelGGL(p2n_colmax_kernel, dim3(256, B), dim3(256), 0, s, n.z[5], n.Ppad, N, n.ftab[5], 256, n.g, n.arg);
@@ -820,7 +851,7 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
     }
     hipStream_t s = (hipStream_t)stream_;
     for (int l = 0; l < 9; ++l) P2N_CHECK_HIP(hipMemsetAsync(dW[l], 0, sizeof(float) * (size_t)n.cin[l] * n.cout[l], s));
-    for (int l = 0; l < 8; ++l) P2N_CHECK_HIP(hipMemsetAsync(db[l], 0, sizeof(float) * n.cout[l], s));   // sum dz = 0 under BN
+    for (int l = 0; l < 8; ++l) P2N_CHECK_HIP(hipMemsetAsync(db[l], 0, sizeof(float) * n.cout[l], s));   // sum dz = 0 under batch-statistics BN
 
     // ---- layer 8 (no BN): dz8 = gemb
     if (256 % E == 0) {
@@ -851,7 +882,7 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
         hipLaunchKernelGGL(p2n_row_stats_kernel<ST_BWD>, dim3(C, STAT_S), dim3(256), 0, s, st);
         P2N_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(p2n_bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, s, n.part, C, STAT_S, n.P,
-                           n.gamma[l], n.ftab[l], dgam[l], dbet[l], n.btab);
+                           n.gamma[l], n.ftab[l], dgam[l], dbet[l], n.btab, n.mode, db[l]);
         P2N_CHECK_HIP(hipGetLastError());
         // weight gradient
         WgArgs w = {};

@@ -1,6 +1,7 @@
 """Autograd bridge of the training path (libp2n_hip.so: p2n_train_forward/backward).
 
-`Point2Net` in train() mode on GPU tensors lands here (reference train.py:109,124,131:
+`Point2Net` in train() mode on GPU tensors -- or in eval() mode with autograd enabled (fine-tuning with
+frozen BatchNorm statistics) -- lands here (reference train.py:109,124,131:
 model.train(); embeddings = model(features); loss.backward()).  One
 torch.autograd.Function covers the whole network: the C library keeps the
 pre-BatchNorm activations in a workspace tensor owned by the autograd context and
@@ -79,20 +80,19 @@ class _Point2NetTrainFn(torch.autograd.Function):
 
 def forward_train(model, x):
     """Train-mode forward of a Point2Net on a GPU tensor (B,N,F) -> (B,N,E) with autograd."""
-    if not model.training:
-        raise NotImplementedError(
-            "autograd through eval-mode BatchNorm (running statistics) is not implemented on the HIP path; "
-            "call model.train(), or wrap inference in torch.no_grad()")
+    eval_stats = not model.training   # eval-mode BatchNorm under autograd: running statistics, left untouched
     if x.requires_grad:
         raise NotImplementedError("the HIP training path does not produce a gradient for the input points")
     x = _rt.require_cuda_f32(x, "x")
-    if x.size(0) * x.size(1) < 2:
+    if not eval_stats and x.size(0) * x.size(1) < 2:
         raise ValueError("Expected more than 1 value per channel when training")   # as torch BatchNorm raises
     order = _params.flat_order()
     sd = dict(model.named_parameters())
     learnables = [sd[k] for k in order if "running" not in k]
     bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
     momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
+    if eval_stats:
+        return _Point2NetTrainFn.apply(x, model, -1.0, True, *learnables)   # momentum < 0: the library's eval-statistics mode
     emb = _Point2NetTrainFn.apply(x, model, momentum, True, *learnables)
     with torch.no_grad():
         for m in bns:
