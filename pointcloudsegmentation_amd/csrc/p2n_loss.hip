@@ -365,7 +365,10 @@ __global__ __launch_bounds__(256) void p2n_smooth_vec_kernel(const float *__rest
     const long pp = live ? p : 0;
     const long base = (pp / N) * (long)N;
     // all neighbour indices of the point with one load (k1 <= 64): lane j holds column j
-    const int myidx = (live && lane < k1) ? idx[pp * k1 + lane] : 0;
+    int myidx = (live && lane < k1) ? idx[pp * k1 + lane] : 0;
+    // an unfilled neighbour slot (-1: fewer than k1 finite distances, i.e. non-finite coordinates) becomes the point
+    // itself -- distance 0, no contribution, and no read outside the cloud
+    if ((unsigned)myidx >= (unsigned)N) myidx = (int)(pp - base);
     // element (v, e) of a lane is channel 64 v + 16 e + l: every load / atomic instruction touches 16
     // consecutive floats (one 64-byte segment) per row
     float ep[V][4], self[V][4];
@@ -457,7 +460,9 @@ __global__ __launch_bounds__(256) void p2n_rev_count_kernel(const int *__restric
     const long p = e / k1;
     const int j = (int)(e % k1);
     if (p >= P || j == 0) return;
-    atomicAdd(&deg[(p / N) * (long)N + idx[e]], 1);
+    int q = idx[e];
+    if ((unsigned)q >= (unsigned)N) q = (int)(p % N);   // unfilled slot: a self edge (weight 0), as everywhere else
+    atomicAdd(&deg[(p / N) * (long)N + q], 1);
 }
 
 // exclusive scan of deg[0..P) -> off[0..P], three launches: per-block scan of 1024 elements, scan of the
@@ -523,7 +528,9 @@ __global__ __launch_bounds__(256) void p2n_rev_fill_kernel(const int *__restrict
     const long p = e / k1;
     const int j = (int)(e % k1);
     if (p >= P || j == 0) return;
-    const long q = (p / N) * (long)N + idx[e];
+    int ql = idx[e];
+    if ((unsigned)ql >= (unsigned)N) ql = (int)(p % N);
+    const long q = (p / N) * (long)N + ql;
     const int slot = atomicSub(&deg[q], 1) - 1;
     rev[off[q] + slot] = (int)(p % N);
 }
@@ -655,7 +662,8 @@ __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__res
     const bool live = p_ < P;
     const long p = live ? p_ : 0;
     const long base = (p / N) * (long)N;
-    const int myidx = lane < k1 ? idx[p * k1 + lane] : 0;
+    int myidx = lane < k1 ? idx[p * k1 + lane] : 0;
+    if ((unsigned)myidx >= (unsigned)N) myidx = (int)(p - base);   // unfilled slot (-1): the point itself, see p2n_smooth_vec_kernel
     const int r0 = off[p], nrev = live ? off[p + 1] - r0 : 0;
     const int k = k1 - 1, total = live ? k + nrev : 0;
     float dsum = 0.f;
