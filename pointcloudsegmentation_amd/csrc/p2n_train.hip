@@ -554,17 +554,37 @@ __global__ __launch_bounds__(256) void p2n_colmax_kernel(const float *__restrict
 }
 
 // out[b][r] = sum_k M[r][k] v[b][k]  (trans=0: M = W[r*ldw + col0 + k]; trans=1: M = W[k*ldw + col0 + r])
+// grid (ceil(R/64), B): a workgroup owns 64 outputs of one cloud.  All 256 threads stage 64 x 64 tiles of M
+// through LDS with coalesced reads; wave 0 then accumulates one output per lane, k ascending in ONE fma chain --
+// the summation order of a plain dot product (the training goldens are sensitive to it: the sum-loss gradient is
+// a difference of large terms).  One thread per output reading its own 2-KB-strided row took 65 us.
 __global__ __launch_bounds__(256) void p2n_small_gemv_kernel(const float *__restrict__ W, int ldw, int col0, int trans,
                                                             const float *__restrict__ v, int K, int R,
                                                             float *__restrict__ out) {
-    const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= R) return;
+    __shared__ float tile[64][65];   // [k][r], padded: conflict-free for both the fill and the walk
+    __shared__ float vs[64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 64;
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float w = trans ? W[(long)k * ldw + col0 + r] : W[(long)r * ldw + col0 + k];
-        acc = fmaf(w, v[(long)b * K + k], acc);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        __syncthreads();
+        // 16 steps of 256 threads = 64 x 64 elements; the fast index follows memory
+        for (int i = 0; i < 16; ++i) {
+            const int slow = wave * 16 + i;
+            int r, k;
+            if (trans) { k = k0 + slow; r = r0 + lane; } else { r = r0 + slow; k = k0 + lane; }
+            float m = 0.f;
+            if (r < R && k < K) m = trans ? W[(long)k * ldw + col0 + r] : W[(long)r * ldw + col0 + k];
+            tile[k - k0][r - r0] = m;
+        }
+        if (wave == 0) vs[lane] = k0 + lane < K ? v[(long)b * K + k0 + lane] : 0.f;
+        __syncthreads();
+        if (wave == 0) {
+            const int kn = min(64, K - k0);
+            for (int k = 0; k < kn; ++k) acc = fmaf(tile[k][lane], vs[k], acc);
+        }
     }
-    out[(long)b * R + r] = acc;
+    if (wave == 0 && r0 + lane < R) out[(long)b * R + r0 + lane] = acc;
 }
 
 // dW[r][col0+k] = sum_b u[b][r] * v[b][k]
@@ -815,7 +835,7 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
         if (l == 5) {
             hipLaunchKernelGGL(p2n_colmax_kernel, dim3(256, B), dim3(256), 0, s, n.z[5], n.Ppad, N, n.ftab[5], 256, n.g, n.arg);
             P2N_CHECK_HIP(hipGetLastError());
-            hipLaunchKernelGGL(p2n_small_gemv_kernel, dim3(1, B), dim3(256), 0, s, n.W[6], 512, 256, 0, n.g, 256, 256, n.bias6c);
+            hipLaunchKernelGGL(p2n_small_gemv_kernel, dim3(4, B), dim3(256), 0, s, n.W[6], 512, 256, 0, n.g, 256, 256, n.bias6c);
             P2N_CHECK_HIP(hipGetLastError());
             if (global_f) P2N_CHECK_HIP(hipMemcpyAsync(global_f, n.g, sizeof(float) * (size_t)B * 256, hipMemcpyDeviceToDevice, s));
         }
@@ -901,7 +921,7 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
             P2N_CHECK_HIP(hipGetLastError());
             hipLaunchKernelGGL(p2n_outer_sum_kernel, dim3(1, 256), dim3(256), 0, s, n.dzsum6, n.g, B, 256, 256, dW[6], 512, 256);
             P2N_CHECK_HIP(hipGetLastError());
-            hipLaunchKernelGGL(p2n_small_gemv_kernel, dim3(1, B), dim3(256), 0, s, n.W[6], 512, 256, 1, n.dzsum6, 256, 256, n.dg);
+            hipLaunchKernelGGL(p2n_small_gemv_kernel, dim3(4, B), dim3(256), 0, s, n.W[6], 512, 256, 1, n.dzsum6, 256, 256, n.dg);
             P2N_CHECK_HIP(hipGetLastError());
         }
         if (l == 0) break;
