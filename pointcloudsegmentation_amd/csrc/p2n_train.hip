@@ -524,7 +524,7 @@ __global__ void p2n_bn_finalize_bwd_kernel(const float *__restrict__ part, int r
     btab[2 * rows + c] = (float)(g * rstd);                                                  // A1
     btab[3 * rows + c] = ev ? 0.f : (float)(-g * rstd * m1 + g * rstd * rstd * mean * m2);  // A2
     btab[4 * rows + c] = ev ? 0.f : (float)(-g * rstd * rstd * m2);                         // A3
-    if (ev) db[c] = (float)(g * rstd * sdy);
+    db[c] = ev ? (float)(g * rstd * sdy) : 0.f;   // batch statistics: sum dz = 0 exactly, the bias in front of a BatchNorm has no gradient
 }
 
 // ---------------------------------------------------------------- global max branch
@@ -871,7 +871,6 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
     }
     hipStream_t s = (hipStream_t)stream_;
     for (int l = 0; l < 9; ++l) P2N_CHECK_HIP(hipMemsetAsync(dW[l], 0, sizeof(float) * (size_t)n.cin[l] * n.cout[l], s));
-    for (int l = 0; l < 8; ++l) P2N_CHECK_HIP(hipMemsetAsync(db[l], 0, sizeof(float) * n.cout[l], s));   // sum dz = 0 under batch-statistics BN
 
     // ---- layer 8 (no BN): dz8 = gemb
     if (256 % E == 0) {
