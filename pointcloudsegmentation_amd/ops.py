@@ -71,6 +71,8 @@ def knn(query: torch.Tensor, ref: torch.Tensor, k: int, return_dist: bool = True
     N = ref.size(1)
     if ref.size(0) != B:
         raise ValueError("batch mismatch")
+    if query.data_ptr() == ref.data_ptr() and query.shape == ref.shape and 1 <= k <= min(N, 64):
+        return knn_self(ref, k, return_dist)      # the cloud against itself: same result, Morton-ordered search
     idx = torch.empty((B, M, k), dtype=torch.int32, device=query.device)
     d2 = torch.empty((B, M, k), dtype=torch.float32, device=query.device) if return_dist else None
     with torch.cuda.device(query.device):
