@@ -22,6 +22,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The wave's number inside its workgroup as a SCALAR: threadIdx.x >> 6 is wave-uniform by construction, but the
+// compiler keeps it (and every row base, loop bound and pointer derived from it) in vector registers unless told.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 __device__ __forceinline__ float block_sum(float v, float *sh) {   // 256 threads
     v = wave_sum(v);
     __syncthreads();
@@ -33,7 +37,7 @@ __device__ __forceinline__ float block_sum(float v, float *sh) {   // 256 thread
 // en = e / max(|e|, eps); rn = 1 / max(|e|, eps).  One wave per point, lanes over channels.
 __global__ __launch_bounds__(256) void p2n_normalize_fwd_kernel(const float *__restrict__ e, long P, int E,
                                                                float *__restrict__ en, float *__restrict__ rn) {
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long p = (long)blockIdx.x * 4 + wave_id();
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
     float s = 0.f;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) void p2n_normalize_bwd_kernel(const float *den
                                                                const float *__restrict__ en,
                                                                const float *__restrict__ rn, long P, int E,
                                                                float *out) {
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long p = (long)blockIdx.x * 4 + wave_id();
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
     float s = 0.f;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(SEG_THREADS) void p2n_seg_lds_kernel(const float *_
                                                          int want_grad, float *__restrict__ rows_out,
                                                          float *__restrict__ pullsum, int cap) {
     extern __shared__ float lacc[];   // [Tb][E] (+ [Tb] hinge sums for MODE 1)
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = wave_id();
     const int c0 = cstart[b], Tb = cstart[b + 1] - c0;
     // a cloud with more instance rows than the LDS copy holds (cap) adds straight into global memory
     const bool priv = Tb <= cap;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(DISC_THREADS) void p2n_disc_cloud_kernel(const floa
     __shared__ float sh[DISC_THREADS / 64];
     const int b = blockIdx.x;
     const int i0 = cstart[b], i1 = cstart[b + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const bool priv = (long)(i1 - i0) * E <= DISC_LDS_FLOATS;
     int ninst = 0;
     for (int i = i0; i < i1; ++i) ninst += bg[i] ? 0 : 1;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void p2n_pull_b_kernel(const float *__restrict
                                                         float *__restrict__ dpull, float *__restrict__ dpush) {
     // gradients w.r.t. the normalised embedding, taken straight back through en = e / |e| (what
     // p2n_normalize_bwd_kernel does for a stored gradient): out = (g - en * <en, g>) * rn
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long p = (long)blockIdx.x * 4 + wave_id();
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
     const int i = inst[p];
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256) void p2n_smooth_vec_kernel(const float *__rest
                                                             long P, int N, int E, int k1, float w,
                                                             float *__restrict__ part, float *__restrict__ den) {
     __shared__ float sh[4];
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long p = (long)blockIdx.x * 4 + wave_id();
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
     const bool live = p < P;
     const long pp = live ? p : 0;
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(256) void p2n_smooth_pull_kernel(const float *__res
     // part != NULL: the forward value rides along -- the distances of the point's own k edges are summed per
     // workgroup into part[blockIdx.x], exactly what p2n_smooth_vec_kernel<V,false> would have written
     __shared__ float sh[4];
-    const long p_ = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long p_ = (long)blockIdx.x * 4 + wave_id();
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
     const bool live = p_ < P;
     const long p = live ? p_ : 0;

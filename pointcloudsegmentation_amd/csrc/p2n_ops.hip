@@ -386,7 +386,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void p2n_ball_query_kernel(const flo
                                                                       const float *__restrict__ new_xyz, int N, int M,
                                                                       float r2, int ns, int32_t *__restrict__ idx) {
     __shared__ __attribute__((aligned(16))) float sx[BQ_TILE], sy[BQ_TILE], sz[BQ_TILE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar, see p2n_knn_sorted_kernel
     const int b = blockIdx.y;
     const long m0 = 2 * ((long)blockIdx.x * BQ_WAVES + wave);
     const float *P = xyz + (long)b * N * 3;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__
                                                                 int32_t *__restrict__ idx, float *__restrict__ d2out,
                                                                 float *__restrict__ wout) {
     __shared__ __attribute__((aligned(16))) float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar, see p2n_knn_sorted_kernel
     const int b = blockIdx.y;
     const long m0 = 2 * ((long)blockIdx.x * KNN_WAVES + wave);
     const bool active = m0 < M;
@@ -751,7 +751,9 @@ __device__ __forceinline__ void knn_insert_key(unsigned long long &lk, unsigned 
 __global__ __launch_bounds__(KSW * 64) void p2n_knn_sorted_kernel(const float4 *__restrict__ sorted,
                                                                   const float4 *__restrict__ boxes, int N, int ntiles, int k,
                                                                   int32_t *__restrict__ idx, float *__restrict__ d2out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave number as a scalar: everything derived from it (the queries' position, their tile, the tile masks'
+    // split) then lives in SGPRs and the tile walk is scalar code
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const long m0 = 2 * ((long)blockIdx.x * KSW + wave);   // position in the ordered copy
     if (m0 >= N) return;                                    // whole wave; the kernel has no barrier
