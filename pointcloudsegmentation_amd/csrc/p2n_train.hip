@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
     __shared__ __attribute__((aligned(16))) float wbuf[2 * TL_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float tab[5 * 256];
     constexpr int KPC = 8 / CT;   // k-tiles per weight chunk
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int p = lane & 31, h = lane >> 5;
     const long pg = ((long)blockIdx.x * 4 + wave) * 32 + p;
     const bool valid = pg < A.P;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__res
 template <int AMODE, int BMODE, int RT, int CT>
 __global__ __launch_bounds__(256) void p2n_wgrad_kernel(WgArgs A) {
     __shared__ __attribute__((aligned(16))) float sa[RT * WG_TILE * WG_LD], sb[CT * WG_TILE * WG_LD];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int r = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
     const int br = blockIdx.y / A.ntc, bc = blockIdx.y % A.ntc;
