@@ -482,7 +482,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void p2n_knn_kernel(const float *__
                                                                 int32_t *__restrict__ idx, float *__restrict__ d2out,
                                                                 float *__restrict__ wout) {
     __shared__ __attribute__((aligned(16))) float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar, see p2n_knn_sorted_kernel
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // (as a scalar: 5 % slower at 1M reference points, 4-10 % faster on small clouds)
     const int b = blockIdx.y;
     const long m0 = 2 * ((long)blockIdx.x * KNN_WAVES + wave);
     const bool active = m0 < M;
