@@ -64,6 +64,18 @@ int p2n_forward_eval(const float *x, int B, int N, int feature_dim, int embeddin
                      float *f1, float *f2, float *f3,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Allocation-free variant of p2n_forward_eval.  NO COUNTERPART IN THE REFERENCE: it exists for callers
+ * that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  Same arguments and results (bit-identical) as p2n_forward_eval, but the workspace is
+ * a device array built into the library (34 MB per GPU, held until the process ends), so the call is
+ * limited to B*ceil(N/128) <= P2N_NOALLOC_MAX_TILES workgroups (32,768 points when N is a multiple of
+ * 128) and returns P2N_EINVAL beyond.  The call allocates nothing (no hipMalloc/hipFree).  All calls on one
+ * GPU share that array: calls that overlap on one GPU (two streams, two threads) race. */
+#define P2N_NOALLOC_MAX_TILES 256
+int p2n_forward_eval_noalloc(const float *x, int B, int N, int feature_dim, int embedding_dim,
+                             const float *packed, float *emb, float *global_f,
+                             float *f1, float *f2, float *f3, void *stream);
+
 /* ---- eval forward in bf16 (opt-in) -------------------------------------------
  * Same contract as p2n_forward_eval (inputs and outputs stay float32) computed on bf16 MFMA
  * with fp32 accumulation (BASELINE north_star: "bf16/fp32 MFMA GEMMs", 2e-2 relative).  Layers 0-2

@@ -36,6 +36,7 @@ SIGNATURES = {
     "p2n_pack_eval_params": (c_int, [c_f, c_int, c_int, c_f, c_vp]),
     "p2n_forward_eval_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "p2n_forward_eval": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    "p2n_forward_eval_noalloc": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp]),
     "p2n_packed_param_count_bf16": (ctypes.c_long, [c_int, c_int]),
     "p2n_pack_eval_params_bf16": (c_int, [c_f, c_int, c_int, c_f, c_vp]),
     "p2n_forward_eval_bf16": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),

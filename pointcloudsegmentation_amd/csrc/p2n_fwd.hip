@@ -26,6 +26,7 @@
 // (global_load_lds_dwordx4, 8 fragments per wave, no staging registers); one
 // __syncthreads() per chunk (8192 MFMA cycles per wave) retires the DMA and frees the
 // other buffer.  fp32 in, fp32 accumulate: exact-f32 MFMA.
+#include <mutex>
 #include "p2n_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -550,9 +551,10 @@ static int allow_big_lds(K kernel, size_t bytes) {
     return P2N_OK;
 }
 
-extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, const float *packed, float *emb,
+static int forward_eval_impl(const float *x, int B, int N, int F, int E, const float *packed, float *emb,
                                 float *global_f, float *f1, float *f2, float *f3, void *workspace,
                                 size_t workspace_bytes, void *stream_) {
+    // shared body of p2n_forward_eval and p2n_forward_eval_noalloc: launches only, no allocation
     P2N_REQUIRE(B >= 0 && N >= 0, "p2n_forward_eval: negative shape B=%d N=%d", B, N);
     P2N_REQUIRE(F >= 1 && F <= 8, "p2n_forward_eval: feature_dim %d not in [1,8]", F);
     P2N_REQUIRE(E >= 1 && E <= 256, "p2n_forward_eval: embedding_dim %d not in [1,256]", E);
@@ -619,4 +621,55 @@ extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, cons
     p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
+}
+
+extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, const float *packed, float *emb,
+                                float *global_f, float *f1, float *f2, float *f3, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    return forward_eval_impl(x, B, N, F, E, packed, emb, global_f, f1, f2, f3, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------ allocation-free variant
+// For callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc): the f3 spill, the per-workgroup channel maxima and the per-cloud layer-6 shift -- the
+// workspace of p2n_forward_eval -- live in a file-scope device array.  Every GPU the library runs on
+// holds its own copy (34 MB) at its own address until the process ends; the address is looked up once
+// per device, with that device current, and only that pointer is ever handed to kernels (the array's
+// name in host code is a host-side stand-in, not a device address).
+#define P2N_NOALLOC_TILE_FLOATS (P2N_WAVES_PER_WG * 256 * P2N_PTS_PER_WAVE + 256)
+#define P2N_NOALLOC_FLOATS ((size_t)P2N_NOALLOC_MAX_TILES * P2N_NOALLOC_TILE_FLOATS + (size_t)P2N_NOALLOC_MAX_TILES * 256)
+static __device__ __align__(256) float scratch[P2N_NOALLOC_FLOATS];
+
+#define P2N_MAX_DEVICES 64
+static float *g_scratch_ptr[P2N_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+extern "C" int p2n_forward_eval_noalloc(const float *x, int B, int N, int F, int E, const float *packed,
+                                        float *emb, float *global_f, float *f1, float *f2, float *f3,
+                                        void *stream) {
+    P2N_REQUIRE(B >= 0 && N >= 0, "p2n_forward_eval_noalloc: negative shape B=%d N=%d", B, N);
+    if (B == 0 || N == 0) return P2N_OK;
+    const long ntiles = (long)B * tiles_per_cloud(N);
+    P2N_REQUIRE(ntiles <= P2N_NOALLOC_MAX_TILES,
+                "p2n_forward_eval_noalloc: B*ceil(N/128) = %ld exceeds the built-in scratch of %d tiles "
+                "(%d points); use p2n_forward_eval with a caller workspace", ntiles, P2N_NOALLOC_MAX_TILES,
+                P2N_NOALLOC_MAX_TILES * P2N_PTS_PER_WG);
+    int dev = -1;
+    P2N_CHECK_HIP(hipGetDevice(&dev));
+    P2N_REQUIRE(dev >= 0 && dev < P2N_MAX_DEVICES, "p2n_forward_eval_noalloc: device ordinal %d out of range", dev);
+    float *ws;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            float *p = nullptr;
+            P2N_CHECK_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+            P2N_REQUIRE(p != nullptr, "p2n_forward_eval_noalloc: hipGetSymbolAddress returned a null address");
+            g_scratch_ptr[dev] = p;
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    // nothing in the scratch has to start at zero: the encoder writes every spill group, partial row and
+    // (through the mid kernel) shift row that this call's head kernel reads
+    return forward_eval_impl(x, B, N, F, E, packed, emb, global_f, f1, f2, f3, ws, sizeof(float) * P2N_NOALLOC_FLOATS,
+                             stream);
 }
