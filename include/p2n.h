@@ -193,6 +193,39 @@ int p2n_pointwise_layer(const float *in, int B, int Cin, long L, const float *W,
                         void *workspace, size_t workspace_bytes, void *stream);
 int p2n_group_max(const float *in, int B, int C, int M, int ns, float *out, void *stream);
 
+/* ---- fused hierarchical levels (no reference counterpart: the north star names set-abstraction and
+ * feature-propagation levels, the reference has none; parity unpinned).  One kernel per level: the grouped
+ * tensor, the interpolated features and every intermediate layer output stay in registers.  Features
+ * between fused levels are POINT-MAJOR: (B,M,C) rows, not (B,C,M).
+ * A level's shared MLP is a chain of nl Conv(k=1)+BatchNorm(eval)+ReLU layers, dims[0..nl] its channel
+ * counts as the module sees them (dims[0] = 3+C for set abstraction, C1+C2 for propagation); kind 0 = set
+ * abstraction (nl 3), 1 = propagation (nl 2), 2 = propagation with the embedding head on top (nl 4, the
+ * last layer a plain Conv).  p2n_level_pack builds the chain's weight image (MFMA fragment order,
+ * BatchNorm folded in double) once per weight change: params_host = HOST array of 6*nl DEVICE pointers
+ * (W (Cout,Cin), bias, bn.weight, bn.bias, running_mean, running_var; the four BatchNorm pointers NULL for
+ * a plain layer); rot = number of leading input columns the kernels consume LAST (3 coordinate columns
+ * for kind 0, the C1 skip columns for kinds 1/2).  p2n_level_packed_floats returns the image size, or -1
+ * when no fused instantiation fits: supported are 3+C <= 136 with mlp <= (128,128,256); C2 = 256 with
+ * C1 <= 128, mlp <= (256,256); C2 = 128 with C1 <= 8, mlp <= (128,128,128,64) -- callers then compose the
+ * level from the operators above. */
+long p2n_level_packed_floats(int kind, int nl, const int *dims, int rot);
+int p2n_level_pack(int kind, int nl, const int *dims, const void *const *params_host, int rot, double eps,
+                   float *packed, void *stream);
+/* Set-abstraction level: xyz rows of ldx floats (first 3 = coordinates), new_xyz (B,M,3), feat rows of ldf
+ * floats (first C = features) or NULL with C = 0, idx (B,M,32) ->
+ * out (B,M,mlp[2]) = max over the 32 neighbours of MLP([xyz[idx]-new_xyz ; feat[idx]]).  ns must be 32. */
+int p2n_sa_level(const float *xyz, int ldx, const float *new_xyz, const float *feat, int ldf,
+                 const int32_t *idx, int B, int C, int N, int M, int ns, const int *mlp,
+                 const float *packed, float *out, void *stream);
+/* Feature-propagation level: idx3/w3 (B,n,3) from p2n_three_nn, feat2 (B,m,C2) coarse features, skip rows
+ * of ld_skip floats (first C1 = the fine points' own features) or NULL with C1 = 0 ->
+ * out (B,n,mlp[nl-1]) = MLP([skip ; sum_j w3_j * feat2[idx3_j]]); nl = 2, or 4 with the head on top. */
+int p2n_fp_level(const int32_t *idx3, const float *w3, const float *feat2, const float *skip, int ld_skip,
+                 int B, int n, int m, int C1, int C2, int nl, const int *mlp, const float *packed,
+                 float *out, void *stream);
+/* new_xyz[b][m] = first three floats of row idx[b][m] of xyz (rows of ldx floats): the centroids FPS picked. */
+int p2n_gather_xyz(const float *xyz, int ldx, const int32_t *idx, int B, int N, int M, float *out, void *stream);
+
 /* ---- embedding clustering ---------------------
  * p2n_normalize_rows: out[i] = emb[i] / (||emb[i]||_2 + 1e-8) in float32, summed in numpy's
  * pairwise order = reference inference.py:124 bit for bit.  emb, out (N,D), 1 <= D <= 256.

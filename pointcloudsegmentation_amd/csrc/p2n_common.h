@@ -98,6 +98,12 @@ __device__ __forceinline__ void p2n_dma_barrier() {
 #define P2N_K_CLUSTER_COUNT 11
 #define P2N_K_CLUSTER_LINK 12
 #define P2N_K_PREP 13
+#define P2N_K_MLP_LAYER 14
+#define P2N_K_GROUP_MAX 15
+#define P2N_K_SA_LEVEL 16
+#define P2N_K_FP_LEVEL 17
+#define P2N_K_LEVEL_PACK 18
+#define P2N_K_GATHER_XYZ 19
 #define P2N_K_COUNT 32
 int p2n_prof_begin(int kernel_id, hipStream_t s);
 void p2n_prof_end(int slot, hipStream_t s);

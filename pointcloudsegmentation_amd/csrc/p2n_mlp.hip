@@ -113,6 +113,7 @@ extern "C" int p2n_pointwise_layer(const float *in, int B, int Cin, long L, cons
     }
     hipStream_t s = (hipStream_t)stream_;
     const int CT = (Cout + 31) / 32;
+    const int ps = p2n_prof_begin(P2N_K_MLP_LAYER, s);
     for (int k0 = 0; k0 < Cin; k0 += 256) {
         const int K = Cin - k0 < 256 ? Cin - k0 : 256;
         const int KT = K <= 32 ? 1 : K <= 64 ? 2 : K <= 128 ? 4 : 8;
@@ -132,6 +133,7 @@ extern "C" int p2n_pointwise_layer(const float *in, int B, int Cin, long L, cons
         }
         P2N_CHECK_HIP(hipGetLastError());
     }
+    p2n_prof_end(ps, s);
     return P2N_OK;
 }
 
@@ -140,8 +142,10 @@ extern "C" int p2n_group_max(const float *in, int B, int C, int M, int ns, float
     const long rows = (long)B * C * M;
     if (rows == 0) return P2N_OK;
     P2N_REQUIRE(in && out, "p2n_group_max: null pointer");
+    const int ps = p2n_prof_begin(P2N_K_GROUP_MAX, (hipStream_t)stream);
     hipLaunchKernelGGL(p2n_group_max_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
                        rows, ns, out);
+    p2n_prof_end(ps, (hipStream_t)stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }

@@ -13,6 +13,7 @@ CPU tensors run a stock-PyTorch composition of the same formulas (same index rul
 fp32 squared distances, lowest index first), which is what the tests compare against
 (parity unpinned by the reference).  Training this variant on the GPU is not implemented.
 """
+import ctypes
 from typing import List, Optional
 
 import torch
@@ -69,6 +70,77 @@ def _gather_points(feat, idx):                              # feat (B,C,N), idx 
     B, C, _ = feat.shape
     flat = idx.reshape(B, 1, -1).expand(B, C, -1)
     return torch.gather(feat, 2, flat).reshape(B, C, *idx.shape[1:])
+
+
+# ------------------------------------------------------------------ fused levels (p2n_sa_level / p2n_fp_level)
+class _LevelImage:
+    """Packed weight image of one fused level's MLP chain (p2n_level_pack), rebuilt only when a
+    parameter or BatchNorm buffer of the chain changed."""
+
+    def __init__(self, kind: int):
+        self.kind, self.key, self.packed, self.dims = kind, None, None, None
+
+    @staticmethod
+    def chain(mlps):
+        """[(conv, bn | None), ...] of the SharedMLP modules in `mlps`, in order."""
+        out = []
+        for mlp in mlps:
+            mods = list(mlp.net)
+            i = 0
+            while i < len(mods):
+                bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+                out.append((mods[i], bn))
+                i += 3 if bn is not None else 1
+        return out
+
+    def supported(self, mlps, rot: int) -> bool:
+        ch = self.chain(mlps)
+        dims = [ch[0][0].in_channels] + [c.out_channels for c, _ in ch]
+        want_plain_last = self.kind == 2
+        for i, (_, bn) in enumerate(ch):
+            plain = bn is None
+            if plain != (want_plain_last and i == len(ch) - 1):
+                return False
+            if bn is not None and (bn.eps != ch[0][1].eps or not bn.track_running_stats or not bn.affine):
+                return False
+        arr = (ctypes.c_int * len(dims))(*dims)
+        return _lib.lib().p2n_level_packed_floats(self.kind, len(ch), arr, rot) >= 0
+
+    def get(self, mlps, rot: int, device) -> torch.Tensor:
+        ch = self.chain(mlps)
+        tensors = []
+        for conv, bn in ch:
+            tensors += [conv.weight, conv.bias]
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [None] * 4
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+        if key != self.key:
+            L = _lib.lib()
+            dims = [ch[0][0].in_channels] + [c.out_channels for c, _ in ch]
+            arr = (ctypes.c_int * len(dims))(*dims)
+            n = L.p2n_level_packed_floats(self.kind, len(ch), arr, rot)
+            if n < 0:
+                raise ValueError(f"no fused level kernel for the chain {dims}")
+            for t in tensors:
+                if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise ValueError("level parameters must be contiguous float32 GPU tensors")
+            table = (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+            packed = torch.empty(n, dtype=torch.float32, device=device)
+            with torch.cuda.device(device):
+                _lib.check(L.p2n_level_pack(self.kind, len(ch), arr, table, rot, float(ch[0][1].eps), packed.data_ptr(),
+                                            _rt.stream_handle(device)), "p2n_level_pack")
+            self.packed, self.key, self.dims = packed, key, dims
+        return self.packed
+
+
+def gather_xyz(rows: torch.Tensor, ld: int, idx: torch.Tensor) -> torch.Tensor:
+    """rows (B,N,ld) with the coordinates in the first three columns, idx (B,M) int32 -> (B,M,3)."""
+    B, N = rows.shape[0], rows.shape[1]
+    M = idx.shape[1]
+    out = torch.empty((B, M, 3), dtype=torch.float32, device=rows.device)
+    with torch.cuda.device(rows.device):
+        _lib.check(_lib.lib().p2n_gather_xyz(rows.data_ptr(), ld, idx.data_ptr(), B, N, M, out.data_ptr(),
+                                             _rt.stream_handle(rows.device)), "p2n_gather_xyz")
+    return out
 
 
 # ------------------------------------------------------------------ shared MLP
@@ -129,6 +201,35 @@ class SetAbstraction(nn.Module):
         super().__init__()
         self.npoint_div, self.radius, self.nsample = npoint_div, radius, nsample
         self.mlp = SharedMLP([in_channels + 3] + mlp)
+        self._image = _LevelImage(0)
+
+    def fused_supported(self) -> bool:
+        return self.nsample == 32 and len(self.mlp.net) == 9 and self._image.supported([self.mlp], 3)
+
+    def forward_rows(self, xyz, rows, ld, feat_off, C):
+        """The level on point-major rows, one fused kernel (p2n_sa_level): xyz (B,N,3) contiguous;
+        rows (B,N,ld) whose first three columns are the coordinates when feat_off > 0 (level 1 reads the
+        input tensor itself: x = [xyz | features]) -- otherwise rows are the C features alone and the
+        coordinates come from xyz.  Returns new_xyz (B,M,3), features (B,M,Cout) point-major."""
+        L = _lib.lib()
+        B, N, _ = xyz.shape
+        M = max(1, N // self.npoint_div)
+        dev = xyz.device
+        fidx = ops.farthest_point_sample(xyz, M)
+        new_xyz = gather_xyz(xyz, 3, fidx)
+        gidx = ops.ball_query(xyz, new_xyz, self.radius, self.nsample)
+        packed = self._image.get([self.mlp], 3, dev)
+        mlp = self._image.dims[1:]
+        out = torch.empty((B, M, mlp[-1]), dtype=torch.float32, device=dev)
+        if feat_off > 0:
+            xyz_ptr, ldx, feat_ptr, ldf = rows.data_ptr(), ld, rows.data_ptr() + 4 * feat_off, ld
+        else:
+            xyz_ptr, ldx, feat_ptr, ldf = xyz.data_ptr(), 3, (rows.data_ptr() if C else None), ld
+        with torch.cuda.device(dev):
+            _lib.check(L.p2n_sa_level(xyz_ptr, ldx, new_xyz.data_ptr(), feat_ptr if C else None, ldf, gidx.data_ptr(),
+                                      B, C, N, M, self.nsample, (ctypes.c_int * 3)(*mlp), packed.data_ptr(),
+                                      out.data_ptr(), _rt.stream_handle(dev)), "p2n_sa_level")
+        return new_xyz, out
 
     def forward(self, xyz, feat: Optional[torch.Tensor]):   # xyz (B,N,3), feat (B,C,N) | None
         B, N, _ = xyz.shape
@@ -166,6 +267,34 @@ class FeaturePropagation(nn.Module):
     def __init__(self, in_channels: int, mlp: List[int]):
         super().__init__()
         self.mlp = SharedMLP([in_channels] + mlp)
+        self._image = _LevelImage(1)
+        self._image_head = _LevelImage(2)
+
+    def fused_supported(self, C1: int, head: Optional["SharedMLP"] = None) -> bool:
+        if head is None:
+            return len(self.mlp.net) == 6 and self._image.supported([self.mlp], C1)
+        return len(self.mlp.net) == 6 and len(head.net) == 4 and self._image_head.supported([self.mlp, head], C1)
+
+    def forward_rows(self, xyz1, xyz2, skip, ld_skip, skip_off, C1, feat2, head: Optional["SharedMLP"] = None):
+        """The level on point-major rows, one fused kernel (p2n_fp_level): xyz1 (B,n,3) fine points, xyz2
+        (B,m,3) coarse points, skip rows (B,n,ld_skip) whose columns skip_off..skip_off+C1-1 are the fine
+        points' own features (None with C1 = 0), feat2 (B,m,C2) coarse features.  With `head` the embedding
+        head runs on top inside the same kernel.  Returns (B,n,Cout) point-major."""
+        L = _lib.lib()
+        B, n, _ = xyz1.shape
+        m, C2 = feat2.shape[1], feat2.shape[2]
+        dev = xyz1.device
+        _, idx3, w3 = ops.three_nn(xyz1, xyz2)
+        image, mlps = (self._image, [self.mlp]) if head is None else (self._image_head, [self.mlp, head])
+        packed = image.get(mlps, C1, dev)
+        mlp = image.dims[1:]
+        out = torch.empty((B, n, mlp[-1]), dtype=torch.float32, device=dev)
+        skip_ptr = skip.data_ptr() + 4 * skip_off if C1 else None
+        with torch.cuda.device(dev):
+            _lib.check(L.p2n_fp_level(idx3.data_ptr(), w3.data_ptr(), feat2.data_ptr(), skip_ptr, ld_skip, B, n, m, C1,
+                                      C2, len(mlp), (ctypes.c_int * len(mlp))(*mlp), packed.data_ptr(), out.data_ptr(),
+                                      _rt.stream_handle(dev)), "p2n_fp_level")
+        return out
 
     def forward(self, xyz1, xyz2, feat1: Optional[torch.Tensor], feat2):
         if xyz1.is_cuda:
@@ -187,6 +316,7 @@ class Point2NetSA(nn.Module):
         super().__init__()
         c = feature_dim - 3
         self.feature_dim, self.embedding_dim = feature_dim, embedding_dim
+        self.fused = True        # GPU eval: fused level kernels (p2n_sa_level / p2n_fp_level); False = per-operator composition
         self.sa1 = SetAbstraction(4, radii[0], nsample, c, [32, 32, 64])
         self.sa2 = SetAbstraction(4, radii[1], nsample, 64, [64, 64, 128])
         self.sa3 = SetAbstraction(4, radii[2], nsample, 128, [128, 128, 256])
@@ -198,6 +328,8 @@ class Point2NetSA(nn.Module):
     def forward(self, x):                                   # (B,N,feature_dim) -> (B,N,E)
         if x.dim() != 3 or x.size(2) != self.feature_dim:
             raise ValueError(f"expected x of shape (B, N, {self.feature_dim}), got {tuple(x.shape)}")
+        if x.is_cuda and self.fused and self._fused_ok():
+            return self._forward_fused(x)
         xyz0 = x[:, :, :3].contiguous()
         f0 = x[:, :, 3:].transpose(1, 2).contiguous() if self.feature_dim > 3 else None
         xyz1, f1 = self.sa1(xyz0, f0)
@@ -207,3 +339,25 @@ class Point2NetSA(nn.Module):
         u1 = self.fp2(xyz1, xyz2, f1, u2)
         u0 = self.fp1(xyz0, xyz1, f0, u1)
         return self.head(u0).transpose(1, 2)
+
+    # ---- GPU eval: one fused kernel per level, features point-major between levels -------------------
+    def _fused_ok(self) -> bool:
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return False      # the per-operator path raises its NotImplementedError for GPU training
+        c = self.feature_dim - 3
+        return (self.sa1.fused_supported() and self.sa2.fused_supported() and self.sa3.fused_supported()
+                and self.fp3.fused_supported(self.sa2.mlp.net[-3].out_channels)
+                and self.fp2.fused_supported(self.sa1.mlp.net[-3].out_channels)
+                and self.fp1.fused_supported(c, self.head))
+
+    def _forward_fused(self, x):
+        x = _rt.require_cuda_f32(x, "x")
+        F = self.feature_dim
+        c = F - 3
+        xyz0 = x[:, :, :3].contiguous()
+        xyz1, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c)                     # level 1 reads x's rows in place
+        xyz2, f2 = self.sa2.forward_rows(xyz1, f1, f1.shape[2], 0, f1.shape[2])
+        xyz3, f3 = self.sa3.forward_rows(xyz2, f2, f2.shape[2], 0, f2.shape[2])
+        u2 = self.fp3.forward_rows(xyz2, xyz3, f2, f2.shape[2], 0, f2.shape[2], f3)
+        u1 = self.fp2.forward_rows(xyz1, xyz2, f1, f1.shape[2], 0, f1.shape[2], u2)
+        return self.fp1.forward_rows(xyz0, xyz1, x, F, 3, c, u1, head=self.head)   # (B,N,E)

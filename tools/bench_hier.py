@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Hierarchical sibling (`Point2NetSA`: FPS + ball query + shared MLPs + three-NN propagation + head)
+eval forward at BASELINE.json configs[1] as literally written: B=16 clouds x N=8192 points.
+
+Prints ONE JSON line: wall ms per forward, per-kernel ms (HIP events the library records around its own
+launches), and for the shared-MLP kernels the achieved TFLOP/s against the dense fp32-MFMA peak
+(157.3 TFLOP/s, MI355X_MICROARCH.md).  Algorithmic FLOPs per level = 2 x MACs of its layers x columns
+(columns = B*M*nsample for a set-abstraction level, B*n for a propagation level), with the module's real
+channel counts (no padding counted).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+from pointcloudsegmentation_amd import _lib  # noqa: E402
+from pointcloudsegmentation_amd.pointnet2 import Point2NetSA  # noqa: E402
+from pointcloudsegmentation_amd.synth import make_batch  # noqa: E402
+
+PEAK = 157.3
+KNAMES = {3: "fps", 4: "ball_query", 5: "knn/three_nn", 6: "gather/sa_group", 7: "three_interpolate",
+          14: "mlp_layer(unfused)", 15: "group_max(unfused)", 16: "sa_level(fused)", 17: "fp_level(fused)",
+          18: "level_pack", 19: "gather_xyz"}
+
+
+def level_flops(model, B, N):
+    """algorithmic FLOPs of every shared-MLP stage of one forward"""
+    def macs(seq):
+        return sum(m.in_channels * m.out_channels for m in seq.net if isinstance(m, torch.nn.Conv1d))
+    out, n = {}, N
+    for name in ("sa1", "sa2", "sa3"):
+        sa = getattr(model, name)
+        m = max(1, n // sa.npoint_div)
+        out[name] = 2 * macs(sa.mlp) * B * m * sa.nsample
+        n = m
+    ns = [N, N // 4, N // 16]
+    out["fp3"] = 2 * macs(model.fp3.mlp) * B * ns[2]
+    out["fp2"] = 2 * macs(model.fp2.mlp) * B * ns[1]
+    out["fp1"] = 2 * macs(model.fp1.mlp) * B * ns[0]
+    out["head"] = 2 * macs(model.head) * B * ns[0]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=16)
+    ap.add_argument("--N", type=int, default=8192)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--unfused", action="store_true", help="force the per-operator composition")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = Point2NetSA(6, 64).eval().to(dev)
+    if a.unfused:
+        model.fused = False
+    x = torch.from_numpy(make_batch(a.B, a.N, seed=5)).to(dev)
+    L = _lib.lib()
+    with torch.no_grad():
+        for _ in range(3):
+            y = model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            y = model(x)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / a.iters
+        L.p2n_profile_select(-1)
+        L.p2n_profile_enable(1)
+        for _ in range(a.iters):
+            model(x)
+        ms = (ctypes.c_float * 32)()
+        cnt = (ctypes.c_int * 32)()
+        L.p2n_profile_collect(32, ms, cnt)
+        L.p2n_profile_enable(0)
+    assert bool(torch.isfinite(y).all())
+    fl = level_flops(model, a.B, a.N)
+    kern = {KNAMES.get(i, str(i)): {"ms_per_forward": ms[i] / a.iters, "launches_per_forward": cnt[i] / a.iters}
+            for i in range(32) if cnt[i]}
+    mlp_ms = sum(ms[i] for i in (14, 16, 17)) / a.iters
+    total_fl = sum(fl.values())
+    out = {"metric": "Point2NetSA eval forward (FPS+ball-query+MLP+3-NN), B=%d x N=%d" % (a.B, a.N),
+           "path": "unfused operators" if a.unfused else "fused levels",
+           "ms_per_forward_wall": 1e3 * wall, "points_per_s": a.B * a.N / wall,
+           "kernels": kern, "kernel_ms_sum": sum(ms) / a.iters,
+           "mlp": {"algorithmic_GFLOP": {k: v / 1e9 for k, v in fl.items()}, "total_GFLOP": total_fl / 1e9,
+                   "ms": mlp_ms, "TFLOP_per_s": total_fl / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None,
+                   "frac_of_fp32_mfma_peak": total_fl / (mlp_ms * 1e-3) / 1e12 / PEAK if mlp_ms else None}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
