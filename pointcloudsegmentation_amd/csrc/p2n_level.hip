@@ -211,15 +211,20 @@ __device__ __forceinline__ void lv_pass(const WS &ws, int f0, const f32x16 (&in)
 }
 
 // Layer 0: the operand comes from a loader in segments of LV_SEG k-groups; segment s+1 is issued before
-// the MFMAs of segment s and finished (arithmetic on the loaded values) after them.
-template <int G0, int CT, class WS, class Loader>
-__device__ __forceinline__ void lv_layer0(const WS &ws, Loader &ld, f32x16 (&acc)[CT]) {
-    constexpr int NSEG = (G0 + LV_SEG - 1) / LV_SEG;
-    f32x4 cur[LV_SEG];
-    typename Loader::Raw raw[LV_SEG];
+// the MFMAs of segment s and finished (arithmetic on the loaded values) after them.  Segment 0 arrives
+// already issued in `raw` (lv_issue0): the set-abstraction kernel issues it one block ahead.
+template <int G0, class Loader>
+__device__ __forceinline__ void lv_issue0(const Loader &ld, typename Loader::Raw (&raw)[LV_SEG]) {
 #pragma unroll
     for (int q = 0; q < LV_SEG; ++q)
         if (q < G0) ld.issue(q, raw[q]);
+}
+
+template <int G0, int CT, class WS, class Loader>
+__device__ __forceinline__ void lv_layer0(const WS &ws, const Loader &ld, typename Loader::Raw (&raw)[LV_SEG],
+                                          f32x16 (&acc)[CT]) {
+    constexpr int NSEG = (G0 + LV_SEG - 1) / LV_SEG;
+    f32x4 cur[LV_SEG];
 #pragma unroll
     for (int q = 0; q < LV_SEG; ++q)
         if (q < G0) cur[q] = ld.finish(q, raw[q]);
@@ -250,16 +255,34 @@ __device__ __forceinline__ void lv_layer0(const WS &ws, Loader &ld, f32x16 (&acc
     }
 }
 
-// max over the 32 lanes of each wave half (one centroid's 32 neighbours); the result is valid in the
-// upper 16-lane row of each half (lanes 16-31 and 48-63).
-__device__ __forceinline__ float lv_half_max(float v) {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));   // row_half_mirror
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));   // row_mirror
-    // row_bcast15 into rows 1 and 3 (row mask 0xA); rows 0 and 2 keep their own value
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false)));
-    return v;
+// Channel maxima of one 32x32 tile over the 32 lanes of each wave half (one centroid's 32 neighbours), as a
+// halving transpose-reduce: at every step lanes pair up inside their 16-lane DPP row (xor 1, xor 2, rotate
+// 4, rotate 8), each lane keeps one register of a pair and takes the partner's copy of it, so 16 registers
+// shrink to 8, 4, 2, 1 with 15 exchanges instead of 64; one ds_swizzle (lane ^ 16, no memory access) then
+// joins the two rows of the half.  Lane i of a row ends up with the maximum of register i, i.e. of channel
+// 32ct + 8(i>>2) + 4h + (i&3).  Values are post-ReLU (>= 0, or -0.0): their bit patterns order as signed
+// integers, and integer max folds the DPP operand into the instruction.
+template <int N, int CTRL>
+__device__ __forceinline__ void lv_halve_max(int (&m)[16], bool upper) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int keep = upper ? m[2 * q + 1] : m[2 * q];
+        const int give = upper ? m[2 * q] : m[2 * q + 1];
+        const int t = __builtin_amdgcn_update_dpp(0, give, CTRL, 0xF, 0xF, true);
+        m[q] = keep > t ? keep : t;
+    }
+}
+
+__device__ __forceinline__ float lv_tile_half_max(const f32x16 v, int lane) {
+    int m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = __float_as_int(v[i]);
+    lv_halve_max<8, 0xB1>(m, lane & 1);    // quad_perm [1,0,3,2]
+    lv_halve_max<4, 0x4E>(m, lane & 2);    // quad_perm [2,3,0,1]
+    lv_halve_max<2, 0x124>(m, lane & 4);   // row_ror:4
+    lv_halve_max<1, 0x128>(m, lane & 8);   // row_ror:8
+    const int t = __builtin_amdgcn_ds_swizzle(m[0], 0x401F);   // bit mode: and 0x1F, or 0, xor 0x10
+    return __int_as_float(m[0] > t ? m[0] : t);
 }
 
 __device__ __forceinline__ f32x4 lv_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -277,30 +300,63 @@ struct SaArgs {
     int ldx, ldf, C, N, M, Cout, vec;
 };
 
+// Layer-0 operand of a set-abstraction level: k < C the neighbour's features, C <= k < C+3 its
+// coordinates relative to the centroid, zero beyond.  issue() only loads; the centroid is subtracted in
+// finish(), so a block's loads can be issued a whole block ahead without anything waiting on them.
+// Exact fit (C == 8*GF, 16-byte aligned rows): groups 0..GF-1 are one 16-byte load per lane, group GF holds
+// the coordinates in the lower wave half.  Any other C takes the per-element path.
+template <int GF>
 struct SaLoader {
     typedef f32x4 Raw;
-    const float *row;      // this lane's neighbour's feature row
-    f32x4 rel;             // (dx,dy,dz,0)
-    int C, h, vec;
+    const float *row;      // this lane's neighbour's feature row (exact: advanced by the lane's half, 4*h floats)
+    const float *xr;       // this lane's neighbour's coordinates
+    f32x4 cen;             // the centroid (x,y,z,0)
+    int C, h, exact;
     __device__ __forceinline__ float pick(int k) const {
         if (k < C) return row[k];
         const int r = k - C;
-        return r == 0 ? rel[0] : r == 1 ? rel[1] : r == 2 ? rel[2] : 0.f;
+        return r < 3 ? xr[r] : 0.f;
     }
     __device__ __forceinline__ void issue(int g, f32x4 &raw) const {
-        const int k0 = 8 * g + 4 * h;
-        if (vec) {
-            if (k0 < C) raw = lv_ld4(row + k0);
-            else if (k0 == C) raw = rel;
+        if (exact) {
+            if (g < GF) raw = lv_ld4(row + 8 * g);
+            else if (g == GF) raw = f32x4{xr[0], xr[1], xr[2], 0.f};
             else raw = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
+            const int k0 = 8 * g + 4 * h;
             raw = f32x4{pick(k0), pick(k0 + 1), pick(k0 + 2), pick(k0 + 3)};
         }
     }
-    __device__ __forceinline__ f32x4 finish(int, const f32x4 &raw) const { return raw; }
+    __device__ __forceinline__ f32x4 finish(int g, const f32x4 &raw) const {
+        if (exact) {
+            if (g != GF) return raw;
+            const f32x4 d = raw - cen;
+            return h == 0 ? d : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int r0 = 8 * g + 4 * h - C;          // position of the quad's first element in the coordinate triple
+        f32x4 o = raw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j;
+            const float cv = r == 0 ? cen[0] : r == 1 ? cen[1] : cen[2];
+            if (r >= 0 && r < 3) o[j] = raw[j] - cv;
+        }
+        return o;
+    }
 };
 
-template <int G0, int CT1, int CT2, int CT3, int P3, bool STREAMED>
+template <class Loader>
+__device__ __forceinline__ void sa_make_loader(const SaArgs &A, int C, long c, int nb, int h, Loader &ld) {
+    const long b = c / A.M;
+    nb = nb < 0 ? 0 : (nb >= A.N ? A.N - 1 : nb);                // indices are clamped, not trusted
+    const float *cr = A.new_xyz + c * 3;
+    ld.xr = A.xyz + (b * A.N + nb) * A.ldx;
+    ld.row = A.feat + (b * A.N + nb) * A.ldf + (A.vec ? 4 * h : 0);
+    ld.cen = f32x4{cr[0], cr[1], cr[2], 0.f};
+    ld.C = C; ld.h = h; ld.exact = A.vec;
+}
+
+template <int G0, int GF, int CT1, int CT2, int CT3, int P3, bool STREAMED, bool PIPE>
 __global__ __launch_bounds__(256, 2) void p2n_sa_level_kernel(SaArgs A) {
     constexpr int F2 = G0 * CT1, F3 = F2 + 4 * CT1 * CT2, NFRAG = F3 + 4 * CT2 * CT3;
     constexpr int NCHUNK = ((NFRAG + P2N_CHUNK - 1) / P2N_CHUNK + 1) / 2 * 2;
@@ -315,27 +371,58 @@ __global__ __launch_bounds__(256, 2) void p2n_sa_level_kernel(SaArgs A) {
     if (STREAMED) ws.stage(0);
     else ws.load_resident(NFRAG);
     for (int i = threadIdx.x; i < TABN; i += 256) tab[i] = A.packed[A.tab + i];
+
+    // PIPE: software pipeline over the workgroup's blocks (4 centroids each): the neighbour index is fetched
+    // two blocks ahead, the first operand segment and the centroid one block ahead (the small levels, whose
+    // block is shorter than two dependent memory round trips).  Otherwise a block loads its own operands.
+    const long nblk = (A.total + P2N_WAVES_PER_WG - 1) / P2N_WAVES_PER_WG;
+    const long last = A.total - 1;
+    long blk = blockIdx.x;
+    long cent = blk * P2N_WAVES_PER_WG + wave;
+    bool valid = cent < A.total;
+    long c = valid ? cent : last;
+    SaLoader<GF> ld;
+    f32x4 raw[LV_SEG];
+    int C = A.C;
+    int nb_next = 0;
+    if (PIPE && blk < nblk) {
+        sa_make_loader(A, C, c, A.idx[c * 32 + p], h, ld);
+        lv_issue0<G0>(ld, raw);
+        if (blk + gridDim.x < nblk) {
+            const long c2 = (blk + gridDim.x) * P2N_WAVES_PER_WG + wave;
+            nb_next = A.idx[(c2 < A.total ? c2 : last) * 32 + p];
+        }
+    }
     if (!STREAMED) p2n_dma_barrier();      // (streamed: the first chunk gate is the barrier)
 
-    const long nblk = (A.total + P2N_WAVES_PER_WG - 1) / P2N_WAVES_PER_WG;
-    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    for (; blk < nblk; blk += gridDim.x) {
         asm volatile("" ::: "memory");   // keeps the LDS weight reads inside the iteration (hoisted, they spill)
-        const long cent = blk * P2N_WAVES_PER_WG + wave;
-        const bool valid = cent < A.total;
-        const long c = valid ? cent : A.total - 1;
-        const long b = c / A.M;
-        int nb = A.idx[c * 32 + p];
-        nb = nb < 0 ? 0 : (nb >= A.N ? A.N - 1 : nb);            // indices are clamped, not trusted
-        const float *xr = A.xyz + (b * A.N + nb) * A.ldx;
-        const float *cr = A.new_xyz + c * 3;
-        SaLoader ld;
-        ld.rel = f32x4{xr[0] - cr[0], xr[1] - cr[1], xr[2] - cr[2], 0.f};
-        ld.row = A.feat + (b * A.N + nb) * A.ldf;
-        ld.C = A.C; ld.h = h; ld.vec = A.vec;
-
+        asm volatile("" : "+s"(C));      // ... and the per-element path's channel predicates
+        if (!PIPE) {
+            cent = blk * P2N_WAVES_PER_WG + wave;
+            valid = cent < A.total;
+            c = valid ? cent : last;
+            sa_make_loader(A, C, c, A.idx[c * 32 + p], h, ld);
+            lv_issue0<G0>(ld, raw);
+        }
         f32x16 a1[CT1];
         lv_zero(a1);
-        lv_layer0<G0, CT1>(ws, ld, a1);
+        lv_layer0<G0, CT1>(ws, ld, raw, a1);
+        // the next block's loads go out here, behind this block's layer-0 MFMAs
+        const bool valid_cur = valid;
+        const long c_cur = c;
+        const long nxt = blk + gridDim.x;
+        if (PIPE && nxt < nblk) {
+            cent = nxt * P2N_WAVES_PER_WG + wave;
+            valid = cent < A.total;
+            c = valid ? cent : last;
+            sa_make_loader(A, C, c, nb_next, h, ld);
+            lv_issue0<G0>(ld, raw);
+            if (nxt + gridDim.x < nblk) {
+                const long c2 = (nxt + gridDim.x) * P2N_WAVES_PER_WG + wave;
+                nb_next = A.idx[(c2 < A.total ? c2 : last) * 32 + p];
+            }
+        }
 #pragma unroll
         for (int ct = 0; ct < CT1; ++ct) a1[ct] = lv_epilogue<true>(a1[ct], tab + S1, tab + H1, ct, h);
         f32x16 a2[CT2];
@@ -343,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void p2n_sa_level_kernel(SaArgs A) {
         lv_pass<CT1, CT2>(ws, F2, a1, a2);
 #pragma unroll
         for (int ct = 0; ct < CT2; ++ct) a2[ct] = lv_epilogue<true>(a2[ct], tab + S2, tab + H2, ct, h);
-        float *orow = A.out + c * A.Cout;
+        float *orow = A.out + c_cur * A.Cout;
 #pragma unroll
         for (int q = 0; q < CT3 / P3; ++q) {
             f32x16 a3[P3];
@@ -352,22 +439,11 @@ __global__ __launch_bounds__(256, 2) void p2n_sa_level_kernel(SaArgs A) {
 #pragma unroll
             for (int cc = 0; cc < P3; ++cc) {
                 const int ct = q * P3 + cc;
-                f32x16 v = lv_epilogue<true>(a3[cc], tab + S3, tab + H3, ct, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = lv_half_max(v[i]);
-                if (valid && p == 16) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ch = 32 * ct + 8 * g + 4 * h;
-                        if ((A.Cout & 3) == 0) {
-                            if (ch < A.Cout) *reinterpret_cast<f32x4 *>(orow + ch) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (ch + j < A.Cout) orow[ch + j] = v[4 * g + j];
-                        }
-                    }
-                }
+                const f32x16 v = lv_epilogue<true>(a3[cc], tab + S3, tab + H3, ct, h);
+                const float mx = lv_tile_half_max(v, lane);
+                // lanes 0-15 of each half hold 16 of the tile's 32 channels: together one 128-byte line
+                const int ch = 32 * ct + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3);
+                if (valid_cur && (lane & 16) == 0 && ch < A.Cout) orow[ch] = mx;
             }
         }
     }
@@ -470,9 +546,11 @@ __global__ __launch_bounds__(256, MINW) void p2n_fp2_level_kernel(FpArgs A) {
         const long col = valid ? col0 : A.total - 1;
         FpLoader<GI> ld;
         fp_make_loader(A, col, h, ld);
+        FpRaw raw[LV_SEG];
+        lv_issue0<G0>(ld, raw);
         f32x16 a1[CT1];
         lv_zero(a1);
-        lv_layer0<G0, CT1>(ws, ld, a1);
+        lv_layer0<G0, CT1>(ws, ld, raw, a1);
 #pragma unroll
         for (int ct = 0; ct < CT1; ++ct) a1[ct] = lv_epilogue<true>(a1[ct], tab + S1, tab + H1, ct, h);
         float *orow = A.out + col * A.Cout;
@@ -512,9 +590,11 @@ __global__ __launch_bounds__(256, 2) void p2n_fp4_level_kernel(FpArgs A) {
         const long col = valid ? col0 : A.total - 1;
         FpLoader<GI> ld;
         fp_make_loader(A, col, h, ld);
+        FpRaw raw[LV_SEG];
+        lv_issue0<G0>(ld, raw);
         f32x16 a1[CT1];
         lv_zero(a1);
-        lv_layer0<G0, CT1>(ws, ld, a1);
+        lv_layer0<G0, CT1>(ws, ld, raw, a1);
 #pragma unroll
         for (int ct = 0; ct < CT1; ++ct) a1[ct] = lv_epilogue<true>(a1[ct], tab + S1, tab + H1, ct, h);
         f32x16 a2[CT2];
@@ -580,7 +660,7 @@ struct LvInst {
 static const LvInst g_inst[] = {
     {0, 0, {3, 1, {1, 1, 2, 0}, {1, 1, 2, 0}, 0}},     // SA: K <= 8,   mlp <= (32, 32, 64)    resident (13 KiB)
     {0, 0, {3, 9, {2, 2, 4, 0}, {2, 2, 4, 0}, 0}},     // SA: K <= 72,  mlp <= (64, 64, 128)   resident (66 KiB)
-    {0, 0, {3, 17, {4, 4, 8, 0}, {4, 4, 4, 0}, 1}},    // SA: K <= 136, mlp <= (128, 128, 256) streamed
+    {0, 0, {3, 17, {4, 4, 8, 0}, {4, 4, 2, 0}, 1}},    // SA: K <= 136, mlp <= (128, 128, 256) streamed
     {1, 32, {2, 40, {8, 4, 0, 0}, {8, 4, 0, 0}, 1}},   // FP: C2 = 256, C1 <= 64,  mlp <= (256, 128)
     {1, 32, {2, 48, {8, 8, 0, 0}, {8, 2, 0, 0}, 1}},   // FP: C2 = 256, C1 <= 128, mlp <= (256, 256)
     {2, 16, {4, 17, {4, 4, 4, 2}, {4, 4, 4, 2}, 1}},   // FP + head: C2 = 128, C1 <= 8, mlp <= (128, 128, 128, 64)
@@ -684,15 +764,15 @@ extern "C" int p2n_sa_level(const float *xyz, int ldx, const float *new_xyz, con
     SaArgs a;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = C ? feat : xyz; a.idx = idx; a.packed = packed; a.out = out;
     a.total = total; a.tab = L.tab; a.ldx = ldx; a.ldf = C ? ldf : ldx; a.C = C; a.N = N; a.M = M; a.Cout = mlp[2];
-    a.vec = C > 0 && (C & 3) == 0 && (ldf & 3) == 0 && ((uintptr_t)feat & 15) == 0;
+    a.vec = C == 8 * (S.G0 - 1) && (C == 0 || ((ldf & 3) == 0 && ((uintptr_t)feat & 15) == 0));   // exact fit
     const size_t lds = lv_lds_bytes(S, L);
     const long nblk = (total + P2N_WAVES_PER_WG - 1) / P2N_WAVES_PER_WG;
     hipStream_t s = (hipStream_t)stream;
     const int ps = p2n_prof_begin(P2N_K_SA_LEVEL, s);
     switch (i) {
-        case 0: LV_LAUNCH((p2n_sa_level_kernel<1, 1, 1, 2, 2, false>), a, nblk, 2048L); break;
-        case 1: LV_LAUNCH((p2n_sa_level_kernel<9, 2, 2, 4, 4, false>), a, nblk, 512L); break;
-        default: LV_LAUNCH((p2n_sa_level_kernel<17, 4, 4, 8, 4, true>), a, nblk, 512L); break;
+        case 0: LV_LAUNCH((p2n_sa_level_kernel<1, 0, 1, 1, 2, 2, false, true>), a, nblk, 2048L); break;
+        case 1: LV_LAUNCH((p2n_sa_level_kernel<9, 8, 2, 2, 4, 4, false, true>), a, nblk, 512L); break;
+        default: LV_LAUNCH((p2n_sa_level_kernel<17, 16, 4, 4, 8, 2, true, false>), a, nblk, 512L); break;
     }
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
