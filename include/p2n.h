@@ -219,10 +219,14 @@ int p2n_sa_level(const float *xyz, int ldx, const float *new_xyz, const float *f
                  const float *packed, float *out, void *stream);
 /* Feature-propagation level: idx3/w3 (B,n,3) from p2n_three_nn, feat2 (B,m,C2) coarse features, skip rows
  * of ld_skip floats (first C1 = the fine points' own features) or NULL with C1 = 0 ->
- * out (B,n,mlp[nl-1]) = MLP([skip ; sum_j w3_j * feat2[idx3_j]]); nl = 2, or 4 with the head on top. */
+ * out (B,n,mlp[nl-1]) = MLP([skip ; sum_j w3_j * feat2[idx3_j]]); nl = 2, or 4 with the head on top.
+ * A level with few points runs layer by layer with its output channels split over the grid (every CU gets a
+ * workgroup); the first layer's output then passes through `workspace` (p2n_fp_level_workspace_bytes; 0 when
+ * the level runs as one kernel, NULL is then fine). */
+size_t p2n_fp_level_workspace_bytes(int B, int n, int C1, int C2, int nl, const int *mlp);
 int p2n_fp_level(const int32_t *idx3, const float *w3, const float *feat2, const float *skip, int ld_skip,
                  int B, int n, int m, int C1, int C2, int nl, const int *mlp, const float *packed,
-                 float *out, void *stream);
+                 float *out, void *workspace, size_t workspace_bytes, void *stream);
 /* new_xyz[b][m] = first three floats of row idx[b][m] of xyz (rows of ldx floats): the centroids FPS picked. */
 int p2n_gather_xyz(const float *xyz, int ldx, const int32_t *idx, int B, int N, int M, float *out, void *stream);
 

@@ -64,7 +64,8 @@ SIGNATURES = {
     "p2n_level_packed_floats": (ctypes.c_long, [c_int, c_int, c_vp, c_int]),
     "p2n_level_pack": (c_int, [c_int, c_int, c_vp, c_vp, c_int, ctypes.c_double, c_f, c_vp]),
     "p2n_sa_level": (c_int, [c_f, c_int, c_f, c_f, c_int, c_i, c_int, c_int, c_int, c_int, c_int, c_vp, c_f, c_f, c_vp]),
-    "p2n_fp_level": (c_int, [c_i, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_f, c_f, c_vp]),
+    "p2n_fp_level_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "p2n_fp_level": (c_int, [c_i, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_f, c_f, c_vp, c_sz, c_vp]),
     "p2n_gather_xyz": (c_int, [c_f, c_int, c_i, c_int, c_int, c_int, c_f, c_vp]),
     "p2n_normalize_rows": (c_int, [c_f, ctypes.c_long, c_int, c_f, c_vp]),
     "p2n_cluster_workspace_bytes": (c_sz, [ctypes.c_long, c_int, c_int]),

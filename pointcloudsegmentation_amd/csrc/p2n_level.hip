@@ -26,7 +26,12 @@
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define CHUNK_FLOATS (P2N_CHUNK * P2N_FRAG_FLOATS)   // 8192 floats = 32 KiB
 #define LV_MAX_LAYERS 4
-#define LV_SEG 4                                       // layer-0 operand groups fetched ahead per step
+#ifndef FP_SEG1
+#define FP_SEG1 4   // operand groups fetched ahead per step, one wave per SIMD
+#endif
+#ifndef FP_SEG2
+#define FP_SEG2 2   // ... two waves per SIMD (256 registers)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -130,6 +135,68 @@ __global__ void p2n_level_pack_kernel(LvPackArgs A, float *__restrict__ packed) 
     packed[i] = v;
 }
 
+// Channel-split images of a two-layer propagation chain, appended to its ordinary image.  A level with few
+// columns (fewer 128-point blocks than CUs) runs layer by layer instead: grid = (column blocks, pairs of output
+// tiles), so that every CU gets a workgroup; the layer-0 operand is then fetched once per tile pair.  Sub-image
+// (layer l, pair y) = the fragments of output tiles 2y and 2y+1 in [g][tile] order, padded to an even number of
+// chunks, followed by 64 scale and 64 shift values.
+struct LvSplit {
+    long base[2];      // float offset of layer l's first sub-image from the image base
+    long stride[2];    // floats per sub-image
+    int pairs[2];      // sub-images of layer l
+    long total;        // floats of the whole image including the split part
+};
+
+static inline LvSplit lv_split_layout(const LvShape &S, const LvLayout &L) {
+    LvSplit X;
+    long o = L.total;
+    for (int l = 0; l < 2; ++l) {
+        long nchunk = ((long)L.G[l] * 2 + P2N_CHUNK - 1) / P2N_CHUNK;
+        nchunk = (nchunk + 1) / 2 * 2;
+        X.base[l] = o;
+        X.stride[l] = nchunk * CHUNK_FLOATS + 128;
+        X.pairs[l] = S.CT[l] / 2;
+        o += X.stride[l] * X.pairs[l];
+    }
+    X.total = o;
+    return X;
+}
+
+__global__ void p2n_level_pack_split_kernel(LvPackArgs A, LvSplit X, float *__restrict__ packed) {
+    const long i = A.L.total + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= X.total) return;
+    const int l = i >= X.base[1] ? 1 : 0;
+    const long r = i - X.base[l];
+    const int y = (int)(r / X.stride[l]);
+    const long q = r % X.stride[l];
+    const long stream_floats = X.stride[l] - 128;
+    float v = 0.f;
+    if (q >= stream_floats) {
+        const int t = (int)(q - stream_floats);
+        const int c = 64 * y + (t & 63);
+        const bool is_shift = t >= 64;
+        if (c < A.cout[l]) {
+            const double bias = A.b[l][c];
+            const double s = (double)A.gamma[l][c] / sqrt((double)A.var[l][c] + A.eps);
+            const double sh = (bias - (double)A.mean[l][c]) * s + (double)A.beta[l][c];
+            v = (float)(is_shift ? sh : s);
+        }
+    } else {
+        const long f = q / P2N_FRAG_FLOATS;
+        const int e = (int)(q % P2N_FRAG_FLOATS);
+        const int lane = e >> 2, j = e & 3;
+        if (f < (long)A.L.G[l] * 2) {
+            const int g = (int)(f >> 1), ct = 2 * y + (int)(f & 1);
+            const int row = 32 * ct + (lane & 31), k = 8 * g + 4 * (lane >> 5) + j;
+            if (row < A.cout[l] && k < A.cin[l]) {
+                const int col = (l == 0) ? (k + A.rot) % A.cin[0] : k;
+                v = A.W[l][(long)row * A.cin[l] + col];
+            }
+        }
+    }
+    packed[i] = v;
+}
+
 // ------------------------------------------------------------------ device helpers
 // The weight stream as a wave sees it.  STREAMED: two 32-KiB chunks in LDS; entering the first fragment
 // of chunk c every wave waits for it (vmcnt(0) + barrier, which also proves that the other buffer is no
@@ -198,29 +265,36 @@ __device__ __forceinline__ void lv_zero(f32x16 (&t)[CT]) {
 // Fragments [g][tile in pass] from stream index f0.
 template <int KT, int P, class WS>
 __device__ __forceinline__ void lv_pass(const WS &ws, int f0, const f32x16 (&in)[KT], f32x16 (&acc)[P]) {
+    // the fragment of step i+1 is read from LDS before the MFMAs of step i issue: a wave alone on its SIMD
+    // otherwise waits out the LDS latency in front of every group of four MFMAs
+    f32x4 a = ws.frag(f0);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int c = 0; c < P; ++c) {
-                const f32x4 a = ws.frag(f0 + (kt * 4 + g) * P + c);
+                const int i = (kt * 4 + g) * P + c;
+                f32x4 an = a;
+                if (i + 1 < KT * 4 * P) an = ws.frag(f0 + i + 1);
+                __builtin_amdgcn_sched_barrier(0);   // or the scheduler sinks the read back to its first use
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[c] = MFMA32(a[j], in[kt][4 * g + j], acc[c]);
+                a = an;
             }
 }
 
-// Layer 0: the operand comes from a loader in segments of LV_SEG k-groups; segment s+1 is issued before
+// Layer 0: the operand comes from a loader in segments of LV_SEG k-groups (fetched ahead per step); segment s+1 is issued before
 // the MFMAs of segment s and finished (arithmetic on the loaded values) after them.  Segment 0 arrives
 // already issued in `raw` (lv_issue0): the set-abstraction kernel issues it one block ahead.
-template <int G0, class Loader>
+template <int G0, int LV_SEG, class Loader>
 __device__ __forceinline__ void lv_issue0(const Loader &ld, typename Loader::Raw (&raw)[LV_SEG]) {
 #pragma unroll
     for (int q = 0; q < LV_SEG; ++q)
         if (q < G0) ld.issue(q, raw[q]);
 }
 
-template <int G0, int CT, class WS, class Loader>
+template <int G0, int CT, int LV_SEG, class WS, class Loader>
 __device__ __forceinline__ void lv_layer0(const WS &ws, const Loader &ld, typename Loader::Raw (&raw)[LV_SEG],
                                           f32x16 (&acc)[CT]) {
     constexpr int NSEG = (G0 + LV_SEG - 1) / LV_SEG;
@@ -228,6 +302,7 @@ __device__ __forceinline__ void lv_layer0(const WS &ws, const Loader &ld, typena
 #pragma unroll
     for (int q = 0; q < LV_SEG; ++q)
         if (q < G0) cur[q] = ld.finish(q, raw[q]);
+    f32x4 a = ws.frag(0);
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         if (s + 1 < NSEG) {
@@ -241,9 +316,12 @@ __device__ __forceinline__ void lv_layer0(const WS &ws, const Loader &ld, typena
             if (g < G0) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    const f32x4 a = ws.frag(g * CT + c);
+                    f32x4 an = a;          // next step's fragment, read ahead of this step's MFMAs
+                    if (g * CT + c + 1 < G0 * CT) an = ws.frag(g * CT + c + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[c] = MFMA32(a[j], cur[q][j], acc[c]);
+                    a = an;
                 }
             }
         }
@@ -381,13 +459,14 @@ __global__ __launch_bounds__(256, 2) void p2n_sa_level_kernel(SaArgs A) {
     long cent = blk * P2N_WAVES_PER_WG + wave;
     bool valid = cent < A.total;
     long c = valid ? cent : last;
+    constexpr int SEG = 4;
     SaLoader<GF> ld;
-    f32x4 raw[LV_SEG];
+    f32x4 raw[SEG];
     int C = A.C;
     int nb_next = 0;
     if (PIPE && blk < nblk) {
         sa_make_loader(A, C, c, A.idx[c * 32 + p], h, ld);
-        lv_issue0<G0>(ld, raw);
+        lv_issue0<G0, SEG>(ld, raw);
         if (blk + gridDim.x < nblk) {
             const long c2 = (blk + gridDim.x) * P2N_WAVES_PER_WG + wave;
             nb_next = A.idx[(c2 < A.total ? c2 : last) * 32 + p];
@@ -403,11 +482,11 @@ __global__ __launch_bounds__(256, 2) void p2n_sa_level_kernel(SaArgs A) {
             valid = cent < A.total;
             c = valid ? cent : last;
             sa_make_loader(A, C, c, A.idx[c * 32 + p], h, ld);
-            lv_issue0<G0>(ld, raw);
+            lv_issue0<G0, SEG>(ld, raw);
         }
         f32x16 a1[CT1];
         lv_zero(a1);
-        lv_layer0<G0, CT1>(ws, ld, raw, a1);
+        lv_layer0<G0, CT1, SEG>(ws, ld, raw, a1);
         // the next block's loads go out here, behind this block's layer-0 MFMAs
         const bool valid_cur = valid;
         const long c_cur = c;
@@ -417,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void p2n_sa_level_kernel(SaArgs A) {
             valid = cent < A.total;
             c = valid ? cent : last;
             sa_make_loader(A, C, c, nb_next, h, ld);
-            lv_issue0<G0>(ld, raw);
+            lv_issue0<G0, SEG>(ld, raw);
             if (nxt + gridDim.x < nblk) {
                 const long c2 = (nxt + gridDim.x) * P2N_WAVES_PER_WG + wave;
                 nb_next = A.idx[(c2 < A.total ? c2 : last) * 32 + p];
@@ -527,7 +606,7 @@ __device__ __forceinline__ void fp_store_tile(float *orow, int Cout, int ct, int
 }
 
 // two layers (both Conv+BN+ReLU); the second in passes of P2 tiles, stored as they finish
-template <int G0, int GI, int CT1, int CT2, int P2, int MINW>
+template <int G0, int GI, int CT1, int CT2, int P2, int MINW, int SEG>
 __global__ __launch_bounds__(256, MINW) void p2n_fp2_level_kernel(FpArgs A) {
     constexpr int F2 = G0 * CT1, NFRAG = F2 + 4 * CT1 * CT2;
     constexpr int NCHUNK = ((NFRAG + P2N_CHUNK - 1) / P2N_CHUNK + 1) / 2 * 2;
@@ -546,11 +625,11 @@ __global__ __launch_bounds__(256, MINW) void p2n_fp2_level_kernel(FpArgs A) {
         const long col = valid ? col0 : A.total - 1;
         FpLoader<GI> ld;
         fp_make_loader(A, col, h, ld);
-        FpRaw raw[LV_SEG];
-        lv_issue0<G0>(ld, raw);
+        FpRaw raw[SEG];
+        lv_issue0<G0, SEG>(ld, raw);
         f32x16 a1[CT1];
         lv_zero(a1);
-        lv_layer0<G0, CT1>(ws, ld, raw, a1);
+        lv_layer0<G0, CT1, SEG>(ws, ld, raw, a1);
 #pragma unroll
         for (int ct = 0; ct < CT1; ++ct) a1[ct] = lv_epilogue<true>(a1[ct], tab + S1, tab + H1, ct, h);
         float *orow = A.out + col * A.Cout;
@@ -569,8 +648,43 @@ __global__ __launch_bounds__(256, MINW) void p2n_fp2_level_kernel(FpArgs A) {
     p2n_dma_barrier();
 }
 
+// one layer of a channel-split level: grid.y = pair of output tiles (64 channels), own sub-image
+template <int G0, int GI, int SEG>
+__global__ __launch_bounds__(256, 2) void p2n_fp1_level_kernel(FpArgs A, long img_stride) {
+    constexpr int NFRAG = G0 * 2;
+    constexpr int NCHUNK = ((NFRAG + P2N_CHUNK - 1) / P2N_CHUNK + 1) / 2 * 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *tab = lds + 2 * CHUNK_FLOATS;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const float *img = A.packed + (long)blockIdx.y * img_stride;
+    const WStream<true, NCHUNK> ws{img, lds, wave, lane};
+    ws.stage(0);
+    if (threadIdx.x < 128) tab[threadIdx.x] = img[(long)NCHUNK * CHUNK_FLOATS + threadIdx.x];
+    const long nblk = (A.total + P2N_PTS_PER_WG - 1) / P2N_PTS_PER_WG;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long col0 = (blk * P2N_WAVES_PER_WG + wave) * P2N_PTS_PER_WAVE + p;
+        const bool valid = col0 < A.total;
+        const long col = valid ? col0 : A.total - 1;
+        FpLoader<GI> ld;
+        fp_make_loader(A, col, h, ld);
+        FpRaw raw[SEG];
+        lv_issue0<G0, SEG>(ld, raw);
+        f32x16 a1[2];
+        lv_zero(a1);
+        lv_layer0<G0, 2, SEG>(ws, ld, raw, a1);
+        float *orow = A.out + col * A.Cout + 64 * blockIdx.y;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const f32x16 v = lv_epilogue<true>(a1[ct], tab, tab + 64, ct, h);
+            if (valid) fp_store_tile<true>(orow, A.Cout - 64 * (int)blockIdx.y, ct, h, v);
+        }
+    }
+    p2n_dma_barrier();
+}
+
 // four layers: the last propagation level with the embedding head on top (Conv+BN+ReLU x3, plain Conv)
-template <int G0, int GI, int CT1, int CT2, int CT3, int CT4>
+template <int G0, int GI, int CT1, int CT2, int CT3, int CT4, int SEG>
 __global__ __launch_bounds__(256, 2) void p2n_fp4_level_kernel(FpArgs A) {
     constexpr int F2 = G0 * CT1, F3 = F2 + 4 * CT1 * CT2, F4 = F3 + 4 * CT2 * CT3, NFRAG = F4 + 4 * CT3 * CT4;
     constexpr int NCHUNK = ((NFRAG + P2N_CHUNK - 1) / P2N_CHUNK + 1) / 2 * 2;
@@ -590,11 +704,11 @@ __global__ __launch_bounds__(256, 2) void p2n_fp4_level_kernel(FpArgs A) {
         const long col = valid ? col0 : A.total - 1;
         FpLoader<GI> ld;
         fp_make_loader(A, col, h, ld);
-        FpRaw raw[LV_SEG];
-        lv_issue0<G0>(ld, raw);
+        FpRaw raw[SEG];
+        lv_issue0<G0, SEG>(ld, raw);
         f32x16 a1[CT1];
         lv_zero(a1);
-        lv_layer0<G0, CT1>(ws, ld, raw, a1);
+        lv_layer0<G0, CT1, SEG>(ws, ld, raw, a1);
 #pragma unroll
         for (int ct = 0; ct < CT1; ++ct) a1[ct] = lv_epilogue<true>(a1[ct], tab + S1, tab + H1, ct, h);
         f32x16 a2[CT2];
@@ -685,7 +799,9 @@ static int lv_kind_layers(int kind) { return kind == 0 ? 3 : kind == 1 ? 2 : kin
 extern "C" long p2n_level_packed_floats(int kind, int nl, const int *dims, int rot) {
     if (!dims || nl != lv_kind_layers(kind)) return -1;
     const int i = lv_find(kind, nl, dims, kind == 0 ? -1 : dims[0] - rot);
-    return i < 0 ? -1 : lv_layout(g_inst[i].S).total;
+    if (i < 0) return -1;
+    const LvLayout L = lv_layout(g_inst[i].S);
+    return kind == 1 ? lv_split_layout(g_inst[i].S, L).total : L.total;
 }
 
 extern "C" int p2n_level_pack(int kind, int nl, const int *dims, const void *const *params_host, int rot,
@@ -721,6 +837,11 @@ extern "C" int p2n_level_pack(int kind, int nl, const int *dims, const void *con
     hipStream_t s = (hipStream_t)stream;
     const int ps = p2n_prof_begin(P2N_K_LEVEL_PACK, s);
     hipLaunchKernelGGL(p2n_level_pack_kernel, dim3((unsigned)((a.L.total + 255) / 256)), dim3(256), 0, s, a, packed);
+    if (kind == 1) {
+        const LvSplit X = lv_split_layout(a.S, a.L);
+        hipLaunchKernelGGL(p2n_level_pack_split_kernel, dim3((unsigned)((X.total - a.L.total + 255) / 256)), dim3(256), 0,
+                           s, a, X, packed);
+    }
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
@@ -779,9 +900,26 @@ extern "C" int p2n_sa_level(const float *xyz, int ldx, const float *new_xyz, con
     return P2N_OK;
 }
 
+// A two-layer level runs channel-split (layer by layer, see LvSplit) when it has fewer 128-point blocks than
+// half the CUs and its middle width fills its tiles exactly; the layer-0 output then passes through `workspace`.
+#define LV_SPLIT_MAX_BLOCKS 128
+static bool lv_split_applies(int inst, long total, const int *mlp) {
+    const LvShape &S = g_inst[inst].S;
+    return g_inst[inst].kind == 1 && (total + P2N_PTS_PER_WG - 1) / P2N_PTS_PER_WG <= LV_SPLIT_MAX_BLOCKS &&
+           mlp[0] == 32 * S.CT[0];
+}
+
+extern "C" size_t p2n_fp_level_workspace_bytes(int B, int n, int C1, int C2, int nl, const int *mlp) {
+    if (B < 1 || n < 1 || !mlp || nl != 2) return 0;
+    const int dims[3] = {C1 + C2, mlp[0], mlp[1]};
+    const int i = lv_find(1, 2, dims, C2);
+    if (i < 0 || !lv_split_applies(i, (long)B * n, mlp)) return 0;
+    return sizeof(float) * (size_t)B * n * mlp[0];
+}
+
 extern "C" int p2n_fp_level(const int32_t *idx3, const float *w3, const float *feat2, const float *skip, int lds_skip,
                             int B, int n, int m, int C1, int C2, int nl, const int *mlp, const float *packed,
-                            float *out, void *stream) {
+                            float *out, void *workspace, size_t workspace_bytes, void *stream) {
     P2N_REQUIRE(B >= 0 && n >= 0 && m >= 1 && C1 >= 0 && C2 >= 4 && mlp && (nl == 2 || nl == 4), "p2n_fp_level: bad shape");
     P2N_REQUIRE((C2 & 3) == 0, "p2n_fp_level: the coarse channel count must be a multiple of 4, got %d", C2);
     int dims[LV_MAX_LAYERS + 1] = {C1 + C2, 0, 0, 0, 0};
@@ -805,10 +943,42 @@ extern "C" int p2n_fp_level(const int32_t *idx3, const float *w3, const float *f
     const long nblk = (total + P2N_PTS_PER_WG - 1) / P2N_PTS_PER_WG;
     hipStream_t s = (hipStream_t)stream;
     const int ps = p2n_prof_begin(P2N_K_FP_LEVEL, s);
+    if (lv_split_applies(i, total, mlp) && workspace && ((uintptr_t)workspace & 15) == 0 &&
+        workspace_bytes >= sizeof(float) * (size_t)total * mlp[0]) {
+        const LvSplit X = lv_split_layout(S, L);
+        const size_t lds = sizeof(float) * (2 * (size_t)CHUNK_FLOATS + 128);
+        const long gx = nblk < 512 ? nblk : 512;
+        FpArgs a0 = a;                       // layer 0: interpolate + skip -> workspace rows of mlp[0] floats
+        a0.packed = packed + X.base[0]; a0.out = (float *)workspace; a0.Cout = mlp[0];
+        FpArgs a1 = a;                       // layer 1: workspace rows -> out
+        a1.packed = packed + X.base[1]; a1.skip = (const float *)workspace; a1.lds = mlp[0]; a1.C1 = mlp[0]; a1.vec = 1;
+        int rc;
+        if (i == 3) {
+            if ((rc = lv_allow_lds(p2n_fp1_level_kernel<40, 32, 4>, lds))) return rc;
+            hipLaunchKernelGGL((p2n_fp1_level_kernel<40, 32, 4>), dim3((unsigned)gx, X.pairs[0]), dim3(256), lds, s, a0, X.stride[0]);
+        } else {
+            if ((rc = lv_allow_lds(p2n_fp1_level_kernel<48, 32, 4>, lds))) return rc;
+            hipLaunchKernelGGL((p2n_fp1_level_kernel<48, 32, 4>), dim3((unsigned)gx, X.pairs[0]), dim3(256), lds, s, a0, X.stride[0]);
+        }
+        if ((rc = lv_allow_lds(p2n_fp1_level_kernel<32, 0, 4>, lds))) return rc;
+        hipLaunchKernelGGL((p2n_fp1_level_kernel<32, 0, 4>), dim3((unsigned)gx, X.pairs[1]), dim3(256), lds, s, a1, X.stride[1]);
+        p2n_prof_end(ps, s);
+        P2N_CHECK_HIP(hipGetLastError());
+        return P2N_OK;
+    }
+    // few blocks (at most one workgroup per CU anyway): the variant compiled for one wave per SIMD, which
+    // may use the whole register file to run further ahead of its MFMAs
+    const bool lone = nblk <= 384;
     switch (i) {
-        case 3: LV_LAUNCH((p2n_fp2_level_kernel<40, 32, 8, 4, 4, 2>), a, nblk, 512L); break;
-        case 4: LV_LAUNCH((p2n_fp2_level_kernel<48, 32, 8, 8, 2, 2>), a, nblk, 512L); break;
-        default: LV_LAUNCH((p2n_fp4_level_kernel<17, 16, 4, 4, 4, 2>), a, nblk, 512L); break;
+        case 3:
+            if (lone) LV_LAUNCH((p2n_fp2_level_kernel<40, 32, 8, 4, 4, 1, FP_SEG1>), a, nblk, 512L);
+            else LV_LAUNCH((p2n_fp2_level_kernel<40, 32, 8, 4, 4, 2, FP_SEG2>), a, nblk, 512L);
+            break;
+        case 4:
+            if (lone) LV_LAUNCH((p2n_fp2_level_kernel<48, 32, 8, 8, 2, 1, FP_SEG1>), a, nblk, 512L);
+            else LV_LAUNCH((p2n_fp2_level_kernel<48, 32, 8, 8, 2, 2, FP_SEG2>), a, nblk, 512L);
+            break;
+        default: LV_LAUNCH((p2n_fp4_level_kernel<17, 16, 4, 4, 4, 2, 4>), a, nblk, 512L); break;
     }
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());

@@ -290,10 +290,13 @@ class FeaturePropagation(nn.Module):
         mlp = image.dims[1:]
         out = torch.empty((B, n, mlp[-1]), dtype=torch.float32, device=dev)
         skip_ptr = skip.data_ptr() + 4 * skip_off if C1 else None
+        mlp_arr = (ctypes.c_int * len(mlp))(*mlp)
+        nbytes = L.p2n_fp_level_workspace_bytes(B, n, C1, C2, len(mlp), mlp_arr)
+        ws = _rt.workspace(nbytes, dev) if nbytes else None
         with torch.cuda.device(dev):
             _lib.check(L.p2n_fp_level(idx3.data_ptr(), w3.data_ptr(), feat2.data_ptr(), skip_ptr, ld_skip, B, n, m, C1,
-                                      C2, len(mlp), (ctypes.c_int * len(mlp))(*mlp), packed.data_ptr(), out.data_ptr(),
-                                      _rt.stream_handle(dev)), "p2n_fp_level")
+                                      C2, len(mlp), mlp_arr, packed.data_ptr(), out.data_ptr(), _rt.ptr(ws),
+                                      ws.numel() if ws is not None else 0, _rt.stream_handle(dev)), "p2n_fp_level")
         return out
 
     def forward(self, xyz1, xyz2, feat1: Optional[torch.Tensor], feat2):

@@ -117,10 +117,12 @@ def test_fused_sa_level_matches_cpu_module(B, N, C, mlp, div):
 
 
 @pytest.mark.parametrize("B,n,m,C1,C2,mlp", [
-    (2, 512, 128, 128, 256, [256, 256]),
+    (2, 512, 128, 128, 256, [256, 256]),        # few blocks: layer by layer, output channels split over the grid
     (2, 1000, 250, 64, 256, [256, 128]),        # ragged: 2000 points = 15 full workgroups + 80
     (1, 130, 40, 0, 256, [200, 100]),           # no skip features, padded channel counts
     (3, 333, 90, 50, 256, [256, 77]),           # skip width that takes the scalar loads, odd Cout
+    (4, 4200, 300, 64, 256, [256, 128]),        # 132 blocks: one two-layer kernel, one wave per SIMD
+    (13, 4000, 1000, 128, 256, [256, 256]),     # 407 blocks: one two-layer kernel, two waves per SIMD
 ])
 def test_fused_fp_level_matches_cpu_module(B, n, m, C1, C2, mlp):
     from pointcloudsegmentation_amd.pointnet2 import FeaturePropagation
