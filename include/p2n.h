@@ -103,7 +103,9 @@ int p2n_forward_eval_bf16(const float *x, int B, int N, int feature_dim, int emb
  * momentum < 0 selects eval-mode BatchNorm for a differentiable forward (model.eval()
  * with autograd enabled, e.g. fine-tuning with frozen statistics): the layers normalise
  * with running_mean/var, which stay untouched, and the backward on that workspace uses
- * dz = gamma*rstd*dy (convolution biases then keep a non-zero gradient). */
+ * dz = gamma*rstd*dy (convolution biases then keep a non-zero gradient).
+ * f1, f2, f3 must be NULL: the training forward keeps only pre-BatchNorm activations and does not produce
+ * the encoder's feature tensors (P2N_EINVAL otherwise); global_f is optional. */
 size_t p2n_train_workspace_bytes(int B, int N, int feature_dim, int embedding_dim);
 int p2n_train_forward(const float *x, int B, int N, int feature_dim, int embedding_dim,
                       const void *const *params_host, float momentum, float *emb, float *global_f,
@@ -134,9 +136,15 @@ int p2n_instance_seg_loss(const float *points, const float *emb, const int32_t *
  * fp32 squared distance ((dx*dx+dy*dy)+dz*dz) without fma, lowest index wins
  * ties). ----------------------------------------------------------------- */
 
-/* Farthest-point sampling: xyz (B,N,3) -> idx (B,M); first sample = start_idx. */
+/* Farthest-point sampling: xyz (B,N,3) -> idx (B,M); first sample = start_idx.
+ * Clouds beyond 12,288 points are sampled by a cluster of workgroups that exchange their winners through
+ * memory every iteration (p2n_fps_workgroups_per_cloud > 1) and must all be resident at once; if another
+ * kernel keeps them from it, the bounded wait of an exchange runs out: the kernel then stores 1 into
+ * *status (device int32, never cleared by the library, so one word can collect many calls; NULL = word 0 of
+ * the workspace, cleared by every call) and fills the rest of the cloud's idx row with start_idx. */
 size_t p2n_fps_workspace_bytes(int B, int N, int M);
-int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx,
+int p2n_fps_workgroups_per_cloud(int B, int N);
+int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, int32_t *status,
             void *workspace, size_t workspace_bytes, void *stream);
 
 /* Ball query: xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample): first nsample

@@ -11,12 +11,13 @@
 
 // Tuning overrides for the sweep tools (tools/fps_sweep.py, tools/sweep_gather.sh), read from the
 // environment once per process: 0 / unset = the built-in choice.
-struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off; };
+struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault; };
 static const P2nTuning &p2n_tuning() {
     static const P2nTuning t = [] {
         auto num = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
         return P2nTuning{num("P2N_FPS_G"), num("P2N_GL_CH"), num("P2N_GL_THREADS"), num("P2N_GL_SPLIT"),
-                         getenv("P2N_GL_OFF") ? 1 : 0};
+                         getenv("P2N_GL_OFF") ? 1 : 0, num("P2N_FPS_T"), num("P2N_FPS_SPIN"),
+                         num("P2N_FPS_FAULT")};
     }();
     return t;
 }
@@ -92,8 +93,9 @@ struct FpsArgs {
     const float *xyz;   // (B,N,3)
     int32_t *idx;       // (B,M)
     u64 *slots;         // [clouds of this launch][M][G][4], zeroed per launch (G > 1 only)
-    int *status;        // 0 ok, 1 = exchange timed out
-    int N, M, G, chunk, start_idx, b0;
+    int *status;        // set to 1 when an exchange timed out (never cleared here)
+    int N, M, G, chunk, start_idx, b0, spin_limit;
+    int fault_it;       // test hook (P2N_FPS_FAULT=k): the cloud's last workgroup skips its publish in iteration k; 0 = off
 };
 
 template <int T, int PPT, bool LDSXYZ>
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
     const unsigned inv0 = 0xFFFFFFFFu - (unsigned)(base + t);
     int kb = 0;   // it % 3
 
-    for (int it = 0; it < A.M; ++it) {
+    int it = 0;
+    for (; it < A.M; ++it) {
         if (g == 0 && t == 0) A.idx[(long)b * A.M + it] = cur;
         if (it + 1 == A.M) break;
         // ---- update running minima (v_min_f32 as the instruction: fminf() would canonicalise its
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
             const int buf = it & 1;
             if (wave == 0) {
                 u64 *slot = A.slots + (((long)(b - A.b0) * A.M + it) * A.G) * 4;
-                if (lane < 4) {
+                if (lane < 4 && !(A.fault_it > 0 && it == A.fault_it && g == A.G - 1)) {
                     u64 payload = k;
                     if (lane > 0) {
                         // a workgroup without real points (li outside its chunk) publishes zeros with its losing key
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
                         ready = v0 != 0ull && (v1 >> 32) != 0ull && (v2 >> 32) != 0ull && (v3 >> 32) != 0ull;
                     }
                     ok = __all(ready);
-                    if (ok || ++spins > FPS_SPIN_LIMIT) break;
+                    if (ok || ++spins > A.spin_limit) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 const bool mine = lane < A.G;
@@ -244,16 +247,37 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
             if (cur < 0) { dead = true; break; }   // uniform: every thread reads the same word
         }
     }
-    if (dead && t == 0) atomicExch(A.status, 1);
+    if (dead) {
+        // an exchange timed out (the cloud's workgroups were not all resident): say so, and leave no index
+        // unwritten -- the rest of the row repeats the start point, so that no consumer gathers out of bounds
+        if (t == 0) atomicExch(A.status, 1);
+        if (g == 0)
+            for (int i = it + 1 + t; i < A.M; i += T) A.idx[(long)b * A.M + i] = A.start_idx;
+    }
 }
 
 // Launch plan: workgroups per cloud, threads, points per thread.
 struct FpsPlan { int G, T, ppt; };
 static const int kFpsPpt256[] = {2, 4, 8, 16, 24, 32, 40, 48};
+static const int kFpsPpt512[] = {2, 4, 8, 12, 16, 24};
 static const int kFpsPpt1024[] = {16, 20};   // only chunks beyond FPS_LDS_POINTS get here
+// compute units of the current device (all workgroups of a launch must be co-resident: one per CU)
+static int fps_cus() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 64;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 64;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 static FpsPlan fps_plan(int B, int N) {
     FpsPlan p = {0, 256, 0};
-    int gmax = 256 / (B < 256 ? B : 256);   // all B*G workgroups must be co-resident
+    const int ncu = fps_cus();
+    int gmax = ncu / (B < ncu ? B : ncu);   // all B*G workgroups must be co-resident
     if (gmax < 1) gmax = 1;
     if (gmax > 64) gmax = 64;
     int G;
@@ -286,9 +310,10 @@ static FpsPlan fps_plan(int B, int N) {
     }
     if (G > gmax) return p;   // does not fit one launch: p.G stays 0
     const int chunk = (N + G - 1) / G;
+    if (p.T == 256 && p2n_tuning().fps_t == 512 && chunk <= 512 * 24) p.T = 512;
     const int need = (chunk + p.T - 1) / p.T;
-    const int *tab = p.T == 256 ? kFpsPpt256 : kFpsPpt1024;
-    const int ntab = p.T == 256 ? 8 : 2;
+    const int *tab = p.T == 256 ? kFpsPpt256 : p.T == 512 ? kFpsPpt512 : kFpsPpt1024;
+    const int ntab = p.T == 256 ? 8 : p.T == 512 ? 6 : 2;
     for (int i = 0; i < ntab; ++i)
         if (tab[i] >= need) { p.ppt = tab[i]; break; }
     if (p.ppt == 0) return p;
@@ -318,8 +343,14 @@ static hipError_t fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
     return hipGetLastError();
 }
 
-extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, void *workspace,
-                       size_t workspace_bytes, void *stream_) {
+extern "C" int p2n_fps_workgroups_per_cloud(int B, int N) {
+    if (B < 1 || N < 1) return 0;
+    const int ncu = fps_cus();
+    return fps_plan(B < ncu ? B : ncu, N).G;
+}
+
+extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, int32_t *status,
+                       void *workspace, size_t workspace_bytes, void *stream_) {
     P2N_REQUIRE(B >= 0 && N >= 1 && M >= 0, "p2n_fps: bad shape B=%d N=%d M=%d", B, N, M);
     P2N_REQUIRE(start_idx >= 0 && start_idx < N, "p2n_fps: start_idx %d outside [0,%d)", start_idx, N);
     if (B == 0 || M == 0) return P2N_OK;
@@ -332,10 +363,12 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
     }
     // sub-batches so that every launch's workgroups are co-resident (<= 256)
     int done = 0;
-    P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));
+    if (!status) P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));   // no private status word: the workspace's
+    const int ncu = fps_cus();
+    const int spin = p2n_tuning().fps_spin > 0 ? p2n_tuning().fps_spin : FPS_SPIN_LIMIT;
     while (done < B) {
         int nb = B - done;
-        if (nb > 256) nb = 256;
+        if (nb > ncu) nb = ncu;
         FpsPlan p = fps_plan(nb, N);
         while (p.G == 0 && nb > 1) {   // cloud too large to be resident with this many clouds in flight
             nb = nb / 2;
@@ -343,7 +376,7 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         }
         P2N_REQUIRE(p.G >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 64 * 1024 * 20);
         FpsArgs a;
-        a.xyz = xyz; a.idx = idx; a.status = (int *)workspace;
+        a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault;
         a.slots = (u64 *)((char *)workspace + 16);
         a.N = N; a.M = M; a.G = p.G; a.chunk = (N + p.G - 1) / p.G; a.start_idx = start_idx; a.b0 = done;
         if (p.G > 1)   // launches run in stream order, so they can share the slot region
@@ -359,6 +392,15 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
                 case 32: e = fps_launch<256, 32, true>(a, nb, stream); break;
                 case 40: e = fps_launch<256, 40, true>(a, nb, stream); break;
                 case 48: e = fps_launch<256, 48, true>(a, nb, stream); break;
+            }
+        } else if (p.T == 512) {
+            switch (p.ppt) {
+                case 2: e = fps_launch<512, 2, true>(a, nb, stream); break;
+                case 4: e = fps_launch<512, 4, true>(a, nb, stream); break;
+                case 8: e = fps_launch<512, 8, true>(a, nb, stream); break;
+                case 12: e = fps_launch<512, 12, true>(a, nb, stream); break;
+                case 16: e = fps_launch<512, 16, true>(a, nb, stream); break;
+                case 24: e = fps_launch<512, 24, true>(a, nb, stream); break;
             }
         } else {
             switch (p.ppt) {

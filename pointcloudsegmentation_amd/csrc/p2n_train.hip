@@ -793,6 +793,8 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
                                  void *workspace, size_t workspace_bytes, void *stream_) {
     TRY(check_common("p2n_train_forward", B, N, F, E));
     P2N_REQUIRE(x && params_host && emb, "p2n_train_forward: null pointer");
+    P2N_REQUIRE(!f1 && !f2 && !f3, "p2n_train_forward: the training forward does not produce f1/f2/f3 (pass NULL; "
+                "p2n_forward_eval returns the encoder features)");
     Net n;
     init_dims(n, B, N, F, E);
     const size_t need = carve(n, nullptr);
@@ -840,7 +842,6 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
             if (global_f) P2N_CHECK_HIP(hipMemcpyAsync(global_f, n.g, sizeof(float) * (size_t)B * 256, hipMemcpyDeviceToDevice, s));
         }
     }
-    (void)f1; (void)f2; (void)f3;
     return P2N_OK;
 }
 

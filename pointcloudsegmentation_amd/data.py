@@ -147,6 +147,7 @@ class DeviceBatchProducer:
         from . import ops
         P = self.ds.num_points
         feats, labs, names, keep = [], [], [], []
+        check = False
         with torch.cuda.stream(stream):
             for i in scene_ids:
                 if self.resample == "random":
@@ -169,6 +170,7 @@ class DeviceBatchProducer:
                 rng = np.random.default_rng([self.seed, self.epoch, i])
                 start = int(rng.integers(0, n))
                 m = min(n, P)
+                check = check or ops.fps_needs_check(1, n)
                 sel = ops.farthest_point_sample(f_d[None, :, :3].contiguous(), m, start)[0].long()
                 if m < P:
                     extra = torch.from_numpy(rng.integers(0, n, P - m)).to(self.device)
@@ -179,7 +181,7 @@ class DeviceBatchProducer:
             batch = {"features": torch.stack(feats), "instance_labels": torch.stack(labs), "scene_id": names}
             ready = torch.cuda.Event()
             ready.record(stream)
-        return {"batch": batch, "ready": ready, "keep": keep}
+        return {"batch": batch, "ready": ready, "keep": keep, "check": check}
 
     def __iter__(self) -> Iterator[dict]:
         order = self._order()
@@ -199,6 +201,12 @@ class DeviceBatchProducer:
             torch.cuda.current_stream(self.device).wait_event(cur["ready"])
             for t in (cur["batch"]["features"], cur["batch"]["instance_labels"]):
                 t.record_stream(torch.cuda.current_stream(self.device))
+            if cur["check"]:
+                # large scenes are resampled by clusters of workgroups that must be co-resident; beside the
+                # caller's kernels they may not be: a timed-out exchange is raised here, before the batch is used
+                cur["ready"].synchronize()
+                from . import ops
+                ops.fps_check(self.device)
             if k + 1 < len(chunks):
                 nxt = self._stage(chunks[k + 1], side)     # runs ahead while the caller computes on `cur`
             yield cur["batch"]

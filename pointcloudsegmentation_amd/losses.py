@@ -44,6 +44,13 @@ class _InstanceSegLossFn(torch.autograd.Function):
         if points.shape != (B, N, 3) or labels.shape != (B, N):
             raise ValueError(f"points {tuple(points.shape)} / embeddings {tuple(emb.shape)} / labels "
                              f"{tuple(labels.shape)} do not agree")
+        if not labels.is_cuda or labels.device != emb_c.device or points.device != emb_c.device:
+            # raw pointers go to the kernels: a host or foreign-device tensor would fault the GPU where
+            # stock PyTorch raises a device-mismatch error
+            raise ValueError(f"points ({points.device}), embeddings ({emb_c.device}) and instance_labels "
+                             f"({labels.device}) must be on the same GPU")
+        if labels.dtype.is_floating_point or labels.dtype == torch.bool:
+            raise TypeError(f"instance_labels must be an integer tensor, got {labels.dtype}")
         inst, cnt, bg, cstart, T = _dense_instances(labels)
         dev = emb_c.device
         want = ctx.needs_input_grad[1]

@@ -27,26 +27,61 @@ def _idx(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+class FpsExchangeTimeout(_lib.P2nError):
+    """A multi-workgroup FPS call gave up waiting for a cloud's other workgroups (they were not all resident,
+    e.g. because another stream's kernels held the compute units).  The indices after that point repeat the
+    start index: valid to gather with, but not a farthest-point sample."""
+
+
+_fps_status = {}   # device index -> int32[1], set to 1 by a timed-out exchange, private to FPS
+
+
+def _fps_status_word(device: torch.device) -> torch.Tensor:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    w = _fps_status.get(key)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=device)
+        _fps_status[key] = w
+    return w
+
+
 def farthest_point_sample(xyz: torch.Tensor, npoint: int, start_idx: int = 0) -> torch.Tensor:
     """xyz (B,N,3) -> (B,npoint) int32.  Sample 0 is start_idx; then argmax of the
-    running min squared distance, lowest index on ties."""
+    running min squared distance, lowest index on ties.  Clouds sampled by several workgroups
+    (fps_needs_check) can fail when those are not co-resident: the failure is recorded on the device
+    and raised by fps_check() -- call it where the indices are consumed on the host side of a
+    synchronisation (DeviceBatchProducer, Point2NetSA and inference.predict do)."""
     xyz = _xyz(xyz, "xyz")
     B, N, _ = xyz.shape
     L = _lib.lib()
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     nbytes = L.p2n_fps_workspace_bytes(B, max(N, 1), max(npoint, 1))
     ws = _rt.workspace(nbytes, xyz.device)
+    status = _fps_status_word(xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.check(L.p2n_fps(xyz.data_ptr(), B, N, npoint, start_idx, idx.data_ptr(), ws.data_ptr(), ws.numel(),
-                             _rt.stream_handle(xyz.device)), "p2n_fps")
+        _lib.check(L.p2n_fps(xyz.data_ptr(), B, N, npoint, start_idx, idx.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                             ws.numel(), _rt.stream_handle(xyz.device)), "p2n_fps")
     return idx
 
 
+def fps_needs_check(B: int, N: int) -> bool:
+    """True when clouds of this size are sampled by several workgroups each (the only way FPS can fail)."""
+    return _lib.lib().p2n_fps_workgroups_per_cloud(max(B, 1), max(N, 1)) > 1
+
+
 def fps_status(device) -> int:
-    """0 = the last multi-workgroup FPS on this device/stream finished its exchanges;
-    1 = an exchange timed out (indices after that point are invalid).  Synchronises."""
-    ws = _rt.workspace(16, torch.device(device))
-    return int(ws[:4].view(torch.int32).item())
+    """0 = every FPS call on this device since the last fps_check finished its exchanges; 1 = one timed
+    out.  Synchronises the device's current stream."""
+    return int(_fps_status_word(torch.device(device)).item())
+
+
+def fps_check(device) -> None:
+    """Raise FpsExchangeTimeout if an FPS call on this device timed out since the last check (and reset)."""
+    w = _fps_status_word(torch.device(device))
+    if int(w.item()) != 0:
+        w.zero_()
+        raise FpsExchangeTimeout("farthest_point_sample: a workgroup exchange timed out (the cloud's workgroups "
+                                 "were not co-resident); the sampled indices are not valid")
 
 
 def ball_query(xyz: torch.Tensor, new_xyz: torch.Tensor, radius: float, nsample: int) -> torch.Tensor:

@@ -341,6 +341,8 @@ class Point2NetSA(nn.Module):
         u2 = self.fp3(xyz2, xyz3, f2, f3)
         u1 = self.fp2(xyz1, xyz2, f1, u2)
         u0 = self.fp1(xyz0, xyz1, f0, u1)
+        if x.is_cuda and ops.fps_needs_check(x.shape[0], x.shape[1]):
+            ops.fps_check(x.device)
         return self.head(u0).transpose(1, 2)
 
     # ---- GPU eval: one fused kernel per level, features point-major between levels -------------------
@@ -363,4 +365,7 @@ class Point2NetSA(nn.Module):
         xyz3, f3 = self.sa3.forward_rows(xyz2, f2, f2.shape[2], 0, f2.shape[2])
         u2 = self.fp3.forward_rows(xyz2, xyz3, f2, f2.shape[2], 0, f2.shape[2], f3)
         u1 = self.fp2.forward_rows(xyz1, xyz2, f1, f1.shape[2], 0, f1.shape[2], u2)
-        return self.fp1.forward_rows(xyz0, xyz1, x, F, 3, c, u1, head=self.head)   # (B,N,E)
+        emb = self.fp1.forward_rows(xyz0, xyz1, x, F, 3, c, u1, head=self.head)   # (B,N,E)
+        if ops.fps_needs_check(x.shape[0], x.shape[1]):
+            ops.fps_check(x.device)      # clouds sampled by workgroup clusters: a timed-out exchange raises here
+        return emb

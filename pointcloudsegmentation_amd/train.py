@@ -58,11 +58,18 @@ class _Point2NetTrainFn(torch.autograd.Function):
         ctx.x = x
         ctx.tensors = tensors     # keeps the (possibly cloned) stats alive for the backward
         ctx.shape = (B, N, F, E)
+        # the backward reads the weights through raw pointers: saving them lets autograd's version check
+        # catch an in-place update between forward and backward, as it would for stock modules
+        ctx.save_for_backward(*learnables)
         return emb
 
     @staticmethod
     def backward(ctx, gemb):
         L = _lib.lib()
+        if ctx.ws is None:
+            raise RuntimeError("Trying to backward through the Point2Net HIP graph a second time: the saved "
+                               "activations were released after the first backward (retain_graph is not supported)")
+        _ = ctx.saved_tensors     # raises if a parameter was modified in place since the forward
         B, N, F, E = ctx.shape
         dev = gemb.device
         gemb = gemb.contiguous()
@@ -90,13 +97,20 @@ def forward_train(model, x):
     sd = dict(model.named_parameters())
     learnables = [sd[k] for k in order if "running" not in k]
     bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
-    momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
+    if any(m.momentum is None for m in bns) and not eval_stats:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not implemented on the "
+                                  "HIP training path")
+    momentum = bns[0].momentum
     if eval_stats:
         return _Point2NetTrainFn.apply(x, model, -1.0, True, *learnables)   # momentum < 0: the library's eval-statistics mode
     emb = _Point2NetTrainFn.apply(x, model, momentum, True, *learnables)
     with torch.no_grad():
         for m in bns:
             m.num_batches_tracked += 1
+    # the kernels updated running_mean/var through raw pointers (no version bump): the eval-mode packed
+    # images built from the old statistics must not be reused
+    model._cache.key = None
+    model.encoder._cache.key = None
     return emb
 
 

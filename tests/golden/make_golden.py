@@ -14,6 +14,8 @@ Runs only in the build container (needs /root/reference); the GPU box gets the
   G4  loss_*.npz          InstanceSegLoss terms (reference losses.py:332-489)
                           and kNN neighbour sets
   G5  edge_*.npz          edge cases (all background, one instance, duplicates)
+  G6  train_gapsafe_*.npz full training step on a cloud whose neighbour sets are stable
+                          under the reference's cdist rounding (noise-free gradients)
 
 No reference source text is stored: only inputs and the numbers it produced.
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
@@ -224,10 +226,91 @@ def g5_edges(model):
     save("edge_b2_n256_s9.npz", **arrs)
 
 
+def gap_safe_cloud(b, side, seed, min_gap=2e-4, k=20):
+    """Jittered anisotropic lattice, normalised like reference inference.py:88-91, re-jittered point by point
+    until every point's (k+1)-th and (k+2)-th nearest distances (self included) differ by more than min_gap:
+    the reference's matmul-form cdist (errors ~1e-6 at these distances) then picks exactly the neighbour
+    SETS exact arithmetic picks, so its loss and gradients carry no neighbour-selection noise."""
+    rng = np.random.default_rng(seed)
+    n = side ** 3
+    g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    out = np.zeros((b, n, 3), np.float32)
+    for i in range(b):
+        step = np.array([1.0, 1.13, 1.29]) * (1.0 + 0.05 * i)
+        base = g * step
+        pts = base + rng.uniform(-0.18, 0.18, base.shape)
+        for _ in range(200):
+            q = pts - pts.mean(0)
+            q = (q / np.abs(q).max()).astype(np.float32)
+            d = np.sqrt(((q[:, None, :].astype(np.float64) - q[None, :, :]) ** 2).sum(-1))
+            ds = np.sort(d, axis=1)
+            bad = np.where(ds[:, k + 1] - ds[:, k] < min_gap)[0]
+            if len(bad) == 0:
+                break
+            pts[bad] = base[bad] + rng.uniform(-0.18, 0.18, (len(bad), 3))
+        else:
+            raise RuntimeError("no gap-safe jitter found")
+        out[i] = q[rng.permutation(n)]
+    return out
+
+
+def g6_gap_safe_training_step(sd):
+    """Full training step (train-mode forward, InstanceSegLoss, backward) on a cloud whose 20-neighbour sets
+    are stable under the reference's cdist rounding: pins model-backward o loss-backward end to end."""
+    b, side, seed = 2, 12, 21
+    xyz = gap_safe_cloud(b, side, seed)
+    n = xyz.shape[1]
+    rng = np.random.default_rng(seed + 1)
+    x = np.concatenate([xyz, rng.uniform(0, 1, (b, n, 3)).astype(np.float32)], axis=2)
+    labels = make_labels(b, n, seed)
+    xt = torch.from_numpy(x)
+    m = Point2Net(6, 64)
+    m.load_state_dict(sd)
+    m.train()
+    crit = ref_losses.InstanceSegLoss(feature_dim=64, delta_v=0.1, delta_d=0.5)
+    emb = m(xt)
+    emb.retain_grad()
+    ld = crit(xt[:, :, :3], emb, torch.from_numpy(labels))
+    ld["total_loss"].backward()
+    # the neighbour sets the reference really used (default matmul-form cdist) must equal the exact ones
+    same = 0
+    for i in range(b):
+        p = xt[i, :, :3]
+        _, idx = torch.cdist(p, p).topk(k=21, dim=1, largest=False)
+        ex = knn_sets_exact(p, 20)
+        same += int((np.sort(idx.numpy(), 1) == np.sort(ex.numpy(), 1)).all(1).sum())
+    assert same == b * n, f"reference neighbour sets differ from the exact ones on {b * n - same} rows"
+    arrs = dict(x=x, labels=labels, emb=emb.detach().contiguous().numpy(), demb=emb.grad.contiguous().numpy())
+    arrs.update({"loss." + k: np.float32(v.item()) for k, v in ld.items()})
+    arrs.update({"gradloss." + k: p.grad.numpy().copy() for k, p in m.named_parameters()})
+    arrs.update({"step1." + k: v for k, v in bn_stats(m).items()})
+    # the same step by the same reference code in float64: separates the two float32 computations' own
+    # rounding (the reference's CPU float32 run above, the GPU's) from a real defect
+    m64 = Point2Net(6, 64)
+    m64.load_state_dict(sd)
+    m64 = m64.double().train()
+    emb64 = m64(xt.double())
+    emb64.retain_grad()
+    ld64 = crit(xt[:, :, :3].double(), emb64, torch.from_numpy(labels))
+    ld64["total_loss"].backward()
+    arrs.update({"loss64." + k: np.float64(v.item()) for k, v in ld64.items()})
+    arrs.update({"gradloss64." + k: p.grad.numpy().astype(np.float32) for k, p in m64.named_parameters()})
+    arrs["demb64"] = emb64.grad.contiguous().numpy().astype(np.float32)
+    save(f"train_gapsafe_b{b}_n{n}_s{seed}.npz", **arrs)
+
+
 if __name__ == "__main__":
+    only = set(sys.argv[1:])
     model, sd = load_ref_model()
-    g1_weights(sd)
-    g2_eval(model)
-    g3_train(sd)
-    g4_losses(model)
-    g5_edges(model)
+    if not only or "g1" in only:
+        g1_weights(sd)
+    if not only or "g2" in only:
+        g2_eval(model)
+    if not only or "g3" in only:
+        g3_train(sd)
+    if not only or "g4" in only:
+        g4_losses(model)
+    if not only or "g5" in only:
+        g5_edges(model)
+    if not only or "g6" in only:
+        g6_gap_safe_training_step(sd)

@@ -45,7 +45,7 @@ def test_host_side_argument_checks_need_no_gpu():
     # Morton-ordered copy (16 B per padded point) + two float4 per 64-point tile; nothing beyond the LDS sort's reach
     assert lib.p2n_knn_self_workspace_bytes(2, 8192) == 2 * 8192 * 16 + 2 * 128 * 32 + 256
     assert lib.p2n_knn_self_workspace_bytes(1, 20000) == 256
-    assert lib.p2n_fps(None, 1, 10, 4, 10, None, None, 0, None) == 1
+    assert lib.p2n_fps(None, 1, 10, 4, 10, None, None, None, 0, None) == 1
     assert lib.p2n_three_nn(None, None, 1, 5, 2, None, None, None, None) == 1
     assert lib.p2n_forward_eval_workspace_bytes(16, 8192, 6, 64) == 4 * (1024 * 4 * 8192 + 1024 * 256 + 16 * 256)
 

@@ -123,3 +123,108 @@ def test_full_training_step_matches_reference(ref_weights):
         worst = max(worst, err)
         assert err < 2e-2, f"{k}: {err:.2e}"     # bounded by the reference's own kNN noise in the smoothness term
     print("worst relative gradient error", worst)
+
+
+def test_full_training_step_gap_safe_cloud(ref_weights):
+    """The chain model-backward o loss-backward at the tightest tolerance the reference itself supports.
+    tests/golden/train_gapsafe_*.npz is a jittered lattice whose 21st/22nd nearest distances differ by > 2e-4
+    at every point, so the reference's matmul-form cdist picked exactly the exact-arithmetic neighbour sets
+    (make_golden.py asserts it): no neighbour-selection noise is left.  Pinned here: the loss terms to 1e-5 /
+    1e-4 and d loss / d emb to 1e-4 of its scale.  For the 34 parameter gradients the fixture also holds the
+    same step run by the same reference code in float64: the reference's own float32 run deviates from it by
+    up to 4e-3 of a tensor's scale (eight BatchNorm backward reductions, ReLU masks and the max-pool routing
+    decided on rounded values), so each gradient must match the float32 reference to 2e-4 or to twice that
+    tensor's float32-vs-float64 deviation, whichever is larger -- and must match the float64 run to 5e-5
+    (measured on MI355X: 3.5e-6; the float32 reference: 4.4e-3)."""
+    from src.models.point2net import Point2Net
+    from test_train_gpu import _check_stats, _grad_scale
+    g = golden("train_gapsafe_b2_n1728_s21.npz")
+    m = Point2Net(6, 64)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref_weights.items()})
+    m = m.cuda().train()
+    x = torch.from_numpy(g["x"]).cuda()
+    emb = m(x)
+    emb.retain_grad()
+    ref_emb = g["emb"]
+    assert np.abs(emb.detach().cpu().numpy() - ref_emb).max() / np.abs(ref_emb).max() < 1e-5
+    _check_stats(m, g, "step1.")
+    out = _crit()(x[:, :, :3].contiguous(), emb, torch.from_numpy(g["labels"]).cuda())
+    assert _rel(out["pull_loss"], g["loss.pull_loss"]) < 1e-5
+    assert _rel(out["push_loss"], g["loss.push_loss"]) < 1e-4
+    assert _rel(out["smoothness_loss"], g["loss.smoothness_loss"]) < 1e-5
+    assert _rel(out["total_loss"], g["loss.total_loss"]) < 1e-5
+    out["total_loss"].backward()
+    d = np.abs(emb.grad.cpu().numpy() - g["demb"]).max() / np.abs(g["demb"]).max()
+    assert d < 1e-4, f"d loss / d emb: {d:.2e}"
+    worst32 = worst64 = noise_max = 0.0
+    for k, p in m.named_parameters():
+        scale = _grad_scale(k, lambda q: g["gradloss64." + q])
+        got = p.grad.cpu().numpy()
+        e32 = np.abs(got - g["gradloss." + k]).max() / scale
+        e64 = np.abs(got - g["gradloss64." + k]).max() / scale
+        noise = np.abs(g["gradloss." + k] - g["gradloss64." + k]).max() / scale     # the reference against itself
+        worst32, worst64, noise_max = max(worst32, e32), max(worst64, e64), max(noise_max, noise)
+        assert e32 < max(2e-4, 2 * noise), f"{k}: vs float32 reference {e32:.2e} (reference's own noise {noise:.2e})"
+        assert e64 < 5e-5, f"{k}: vs float64 reference {e64:.2e} (float32 reference: {noise:.2e})"
+    print(f"gap-safe cloud: worst gradient error vs float32 reference {worst32:.2e}, vs float64 reference "
+          f"{worst64:.2e}; float32 reference vs float64 reference {noise_max:.2e}; d loss/d emb {d:.2e}")
+
+
+def test_loss_matches_reference_golden_at_8192(ref_weights):
+    """tests/golden/loss_b2_n8192_s5.npz: the loss shape of the training configuration (N = 8192, reference
+    configs/training_config.yaml:36).  The fixture stores the seed, labels, loss terms and every 64th row of
+    emb / d loss / d emb; the embeddings are recomputed here by the eval forward (checked against the stored
+    rows first)."""
+    from pointcloudsegmentation_amd.synth import make_batch
+    from src.models.point2net import Point2Net
+    g = golden("loss_b2_n8192_s5.npz")
+    x = torch.from_numpy(make_batch(2, 8192, int(g["seed"]))).cuda()
+    m = Point2Net(6, 64)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref_weights.items()})
+    m = m.cuda().eval()
+    with torch.no_grad():
+        emb = m(x).contiguous()
+    ref_rows = g["emb_stride64"]
+    assert np.abs(emb[:, ::64].cpu().numpy() - ref_rows).max() / np.abs(ref_rows).max() < 1e-5
+    emb.requires_grad_(True)
+    out = _crit()(x[:, :, :3].contiguous(), emb, torch.from_numpy(g["labels"]).cuda())
+    assert _rel(out["pull_loss"], g["loss.pull_loss"]) < 1e-4
+    assert _rel(out["push_loss"], g["loss.push_loss"]) < 1e-4
+    assert _rel(out["smoothness_loss"], g["loss.smoothness_loss"]) < 2e-3   # reference kNN noise, see test_loss_oracle
+    assert _rel(out["total_loss"], g["loss.total_loss"]) < 1e-3
+    out["total_loss"].backward()
+    ref = g["demb_stride64"]
+    d = np.abs(emb.grad[:, ::64].cpu().numpy() - ref)
+    assert np.median(d.max(-1)) / np.abs(ref).max() < 1e-5
+    assert d.max() / np.abs(ref).max() < 2e-2
+
+
+def test_smoothness_on_duplicated_points_matches_reference():
+    """reference losses.py:475-479 assumes column 0 of topk(k+1) is the point itself; with every point
+    duplicated (edge_b2_n256_s9.npz: dup.*) that is a tie between the point and its copy.  The exact-arithmetic
+    rule of p2n_knn_self (distance, then lowest index) reproduces the reference's value to 2e-4 (measured);
+    asserted at 1e-3.  The value is assembled from the GPU neighbour indices because the fixture was produced
+    by SmoothnessLoss on the raw (not normalised) embeddings."""
+    from pointcloudsegmentation_amd import ops
+    g = golden("edge_b2_n256_s9.npz")
+    pts = torch.from_numpy(np.ascontiguousarray(g["dup.x"][:, :, :3])).cuda()
+    emb = torch.from_numpy(g["emb"]).cuda().double()
+    idx = ops.knn_self(pts, 21, return_dist=False).long()[:, :, 1:]          # column 0 dropped, as the reference does
+    B, N, _ = idx.shape
+    tot = 0.0
+    for b in range(B):
+        nb = emb[b][idx[b]]                                                   # (N,20,E)
+        tot += float(torch.norm(nb - emb[b].unsqueeze(1), p=2, dim=2).mean())
+    got = tot / B
+    assert _rel(got, g["dup.smoothness"]) < 1e-3, (got, float(g["dup.smoothness"]))
+
+
+def test_loss_rejects_labels_on_another_device():
+    """Raw pointers go to the kernels: labels left on the host (a DataLoader batch not moved to the GPU) must
+    raise like stock PyTorch's device-mismatch error, not fault the GPU."""
+    pts = torch.rand(1, 64, 3, device="cuda")
+    emb = torch.rand(1, 64, 64, device="cuda", requires_grad=True)
+    with pytest.raises(ValueError, match="same GPU"):
+        _crit()(pts, emb, torch.zeros(1, 64, dtype=torch.long))
+    with pytest.raises(TypeError):
+        _crit()(pts, emb, torch.zeros(1, 64, device="cuda"))

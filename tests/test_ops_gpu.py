@@ -378,3 +378,46 @@ def test_sa_group_variants(B, C, N, M, ns):
         if C:
             want[b, 3:] = feat[b][:, idx[b].reshape(-1)].reshape(C, M, ns)
     np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+def test_fps_exchange_timeout_is_loud_and_indices_stay_in_range():
+    """The multi-workgroup FPS needs all workgroups of a cloud resident at once.  When an exchange
+    times out (forced here: P2N_FPS_FAULT makes one workgroup skip its publish in iteration 5, with a
+    small spin limit), the call must (1) leave only valid indices behind, (2) keep the correct prefix,
+    (3) raise FpsExchangeTimeout from fps_check(), and (4) keep its status out of the shared workspace:
+    another workspace user in between must not clear it.  Runs in a child process because the tuning
+    overrides are read once per process."""
+    import os
+    import subprocess
+    import sys
+    child = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from pointcloudsegmentation_amd import ops
+from pointcloudsegmentation_amd.synth import make_batch
+from oracle import oracle
+xyz = np.ascontiguousarray(make_batch(2, 40000, 3)[:, :, :3])
+xg = torch.from_numpy(xyz).cuda()
+assert ops.fps_needs_check(2, 40000)
+idx = ops.farthest_point_sample(xg, 64, 7)
+ops.knn_self(xg[:, :4096].contiguous(), 8)            # another user of the shared per-stream workspace
+got = idx.cpu().numpy()
+assert got.min() >= 0 and got.max() < 40000, "indices out of range after a timeout"
+want = oracle.fps(xyz, 6, 7)
+assert (got[:, :6] == want).all(), "prefix before the timeout must be the real sample"
+assert (got[:, 6:] == 7).all(), "rest of the row repeats the start index"
+assert ops.fps_status("cuda") == 1
+try:
+    ops.fps_check("cuda")
+except ops.FpsExchangeTimeout:
+    print("RAISED")
+assert ops.fps_status("cuda") == 0                    # the check resets the word
+ok = ops.farthest_point_sample(xg[:, :8192].contiguous(), 32, 0)   # single workgroup per cloud: cannot time out
+ops.fps_check("cuda")
+assert (ok.cpu().numpy() == oracle.fps(xyz[:, :8192], 32, 0)).all()
+print("DONE")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, P2N_FPS_FAULT="5", P2N_FPS_SPIN="2000")
+    r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RAISED" in r.stdout and "DONE" in r.stdout, r.stdout + r.stderr
