@@ -15,9 +15,12 @@ scaling is weak and `value` = points all ranks processed / max-over-ranks time.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      for the dominant kernel, from HIP events recorded around every kernel
                 launch inside the timed region (libp2n's p2n_profile_* hooks)
-  cpu_baseline  the CPU oracle (oracle/p2n_oracle.c, a port) timed on this host
-  cpu_torch     the same drop-in module run on the host with stock PyTorch ops
+  cpu_baseline  the drop-in module on CPU tensors: stock Conv1d/BatchNorm1d/ReLU, the reference's own op
+                sequence (its Python files do not travel to the GPU box), timed on this host
+  cpu_port      the CPU oracle (oracle/p2n_oracle.c, double accumulation) timed on this host
   fps           farthest-point sampling of one 40k-point scene (the metric's second half)
+  hier          the hierarchical sibling (FPS + ball query + shared MLPs + three-NN propagation) at the
+                same B=16 x N=8192: ms per forward and the shared-MLP kernels against the fp32 MFMA peak
 """
 import argparse
 import ctypes
@@ -90,9 +93,10 @@ def cpu_baselines(x_np):
             m(xt)
             ts.append(time.perf_counter() - t)
     dt = sorted(ts)[1]
-    tcpu = {"value": x_np.shape[0] * x_np.shape[1] / dt, "unit": "points/s", "cores": threads, "kind": "torch-cpu",
+    tcpu = {"value": x_np.shape[0] * x_np.shape[1] / dt, "unit": "points/s", "cores": threads, "kind": "port",
             "sample": f"drop-in module on CPU tensors (stock Conv1d/BatchNorm1d/ReLU = the reference's op "
-                      f"sequence), median of 3 full steps, {dt:.3f} s"}
+                      f"sequence, reference point2net.py:36-48,67-87), median of 3 full steps of "
+                      f"{x_np.shape[0]}x{x_np.shape[1]} points, {dt:.3f} s"}
     return port, tcpu
 
 
@@ -112,8 +116,17 @@ def fps_leg(device):
     e1.record()
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / reps
+    # eight scenes in one call: the per-iteration exchange latency is shared by the clouds in flight
+    xyz8 = torch.from_numpy(np.ascontiguousarray(make_batch(8, 40000, 9)[:, :, :3])).to(device)
+    ops.farthest_point_sample(xyz8, npoint)
+    torch.cuda.synchronize(device)
+    e0.record()
+    ops.farthest_point_sample(xyz8, npoint)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms8 = e0.elapsed_time(e1)
     return {"ms_per_40k_scene": ms, "npoint": npoint, "us_per_sample": 1e3 * ms / npoint,
-            "status": ops.fps_status(device)}
+            "ms_per_40k_scene_batch_of_8": ms8 / 8, "status": ops.fps_status(device)}
 
 
 def bf16_leg(model, x, lib, steps):
@@ -147,13 +160,15 @@ def bf16_leg(model, x, lib, steps):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of this workload's kernel, from the committed PMC summary (counters
-    cannot be read from inside the process); None when the file is absent."""
+    """(HBM bytes per launch, provenance) of this workload's kernel from the committed PMC summary (counters
+    cannot be read from inside the process); (None, None) when the file is absent.  The provenance names the
+    commit whose kernels were measured, so a stale figure shows."""
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["bytes_per_launch"].get(kernel)
+            d = json.load(f)
+        return d["bytes_per_launch"].get(kernel), f"{d.get('source', '?')}; kernels as of commit {d.get('commit', '?')}"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def main():
@@ -163,6 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-fps", action="store_true", help="skip the FPS leg")
+    ap.add_argument("--no-hier", action="store_true", help="skip the hierarchical-sibling leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -250,7 +266,7 @@ def main():
             "kernels_ms": {k: v[0] for k, v in kernels.items() if v[1]},
             "roofline": {"bound": "mfma", "kernel": f"p2n_{dom}_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic(dom),
+                         "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
                          "note": f"{FLOP_PER_PT[dom]} algorithmic FLOP/pt x {pts_step} pts per launch / "
                                  f"{dom_ms:.4f} ms mean launch (HIP events on the launch stream, {kernels[dom][1]} launches); "
                                  "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes "
@@ -260,10 +276,14 @@ def main():
             out["bf16"] = bf16_leg(model, x, lib, args.steps)
             if not args.no_fps:
                 out["fps"] = fps_leg(device)
+            if not args.no_hier:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import bench_hier
+                out["hier"] = bench_hier.run(B_PER_GPU, N_POINTS, iters=20)
             if not args.no_cpu:
                 port, tcpu = cpu_baselines(x_np)
-                out["cpu_baseline"] = port
-                out["cpu_torch"] = tcpu
+                out["cpu_baseline"] = tcpu
+                out["cpu_port"] = port
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -18,28 +18,56 @@ import torch
 import torch.distributed as dist
 
 
-def _flat_grads(params: List[torch.nn.Parameter]) -> torch.Tensor:
-    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+def _all_reduce_mean(flat: torch.Tensor, world: int) -> None:
+    """In-place mean over ranks.  A backend without support for device tensors (a gloo build without it)
+    gets the bucket through a host copy; RCCL ("nccl") and gloo-with-devices reduce it where it is."""
+    try:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    except RuntimeError:
+        if not flat.is_cuda:
+            raise
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    flat.div_(world)
+
+
+def _shared_bucket(grads: List[torch.Tensor]):
+    """The flat buffer the gradients are views of (train.py allocates one per backward), or None."""
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() or not g.is_contiguous() for g in grads):
+        return None
+    return torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(st)
+
+
+def _reduce_through_bucket(tensors: List[torch.Tensor], world: int) -> None:
+    """Tensors that do not share a buffer (CPU modules, foreign gradients): one bucket, filled and emptied
+    with fused multi-tensor copies."""
+    flat = torch.empty(sum(t.numel() for t in tensors), dtype=tensors[0].dtype, device=tensors[0].device)
+    views = [v.view_as(t) for v, t in zip(flat.split([t.numel() for t in tensors]), tensors)]
+    torch._foreach_copy_(views, tensors)
+    _all_reduce_mean(flat, world)
+    torch._foreach_copy_(tensors, views)
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int = None) -> None:
-    """Average .grad over all ranks with one all-reduce of one flat fp32 bucket."""
+    """Average .grad over all ranks with ONE all-reduce of one flat fp32 bucket.  After a backward through
+    the HIP training path the gradients already ARE views of one flat buffer: it is reduced in place."""
     params = [p for p in params if p.requires_grad]
     if not dist.is_available() or not dist.is_initialized():
         return
     world = world_size or dist.get_world_size()
     if world == 1:
         return
-    bucket = _flat_grads(params)
-    dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
-    bucket.div_(world)
-    off = 0
     for p in params:
-        n = p.numel()
         if p.grad is None:
-            p.grad = torch.empty_like(p)
-        p.grad.copy_(bucket[off:off + n].view_as(p))
-        off += n
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
+    bucket = _shared_bucket(grads)
+    if bucket is not None:
+        _all_reduce_mean(bucket, world)
+    else:
+        _reduce_through_bucket(grads, world)
 
 
 def sync_bn_buffers(model: torch.nn.Module) -> None:
@@ -47,13 +75,13 @@ def sync_bn_buffers(model: torch.nn.Module) -> None:
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return
     bufs = [b for n, b in model.named_buffers() if "running" in n]
-    flat = torch.cat([b.reshape(-1) for b in bufs])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(dist.get_world_size())
-    off = 0
-    for b in bufs:
-        b.copy_(flat[off:off + b.numel()].view_as(b))
-        off += b.numel()
+    _reduce_through_bucket(bufs, dist.get_world_size())
+    cache = getattr(model, "_cache", None)
+    if cache is not None:                 # in-place foreach copies: make sure the eval image is rebuilt
+        cache.key = None
+        enc = getattr(model, "encoder", None)
+        if enc is not None and getattr(enc, "_cache", None) is not None:
+            enc._cache.key = None
 
 
 def train_step(model, criterion, optimizer, features, labels, max_norm: float = 1.0):

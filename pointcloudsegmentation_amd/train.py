@@ -76,7 +76,15 @@ class _Point2NetTrainFn(torch.autograd.Function):
         order = _params.flat_order()
         learn_keys = [k for k in order if "running" not in k]
         sd = dict(zip(order, ctx.tensors))
-        grads = [torch.empty_like(sd[k]) for k in learn_keys]
+        # one flat buffer, the 34 gradients are views of it (each on a 256-byte boundary): autograd installs the
+        # views as .grad, and parallel.allreduce_gradients reduces the buffer in place -- no gather, no copy-back
+        sizes = [sd[k].numel() for k in learn_keys]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads = [flat[o:o + n].view_as(sd[k]) for o, n, k in zip(offs, sizes, learn_keys)]
         with torch.cuda.device(dev):
             _lib.check(L.p2n_train_backward(ctx.x.data_ptr(), gemb.data_ptr(), B, N, F, E, _ptr_table(ctx.tensors),
                                             _ptr_table(grads), ctx.ws.data_ptr(), ctx.ws.numel(),

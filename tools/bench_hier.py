@@ -47,6 +47,47 @@ def level_flops(model, B, N):
     return out
 
 
+def run(B=16, N=8192, iters=20, unfused=False):
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(0)
+    model = Point2NetSA(6, 64).eval().to(dev)
+    if unfused:
+        model.fused = False
+    x = torch.from_numpy(make_batch(B, N, seed=5)).to(dev)
+    L = _lib.lib()
+    with torch.no_grad():
+        for _ in range(3):
+            y = model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            y = model(x)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters
+        L.p2n_profile_select(-1)
+        L.p2n_profile_enable(1)
+        for _ in range(iters):
+            model(x)
+        ms = (ctypes.c_float * 32)()
+        cnt = (ctypes.c_int * 32)()
+        L.p2n_profile_collect(32, ms, cnt)
+        L.p2n_profile_enable(0)
+    assert bool(torch.isfinite(y).all())
+    fl = level_flops(model, B, N)
+    kern = {KNAMES.get(i, str(i)): {"ms_per_forward": ms[i] / iters, "launches_per_forward": cnt[i] / iters}
+            for i in range(32) if cnt[i]}
+    mlp_ms = sum(ms[i] for i in (14, 16, 17)) / iters
+    total_fl = sum(fl.values())
+    return {"metric": "Point2NetSA eval forward (FPS+ball-query+MLP+3-NN), B=%d x N=%d" % (B, N),
+            "path": "per-operator composition" if unfused else "fused levels",
+            "ms_per_forward_wall": 1e3 * wall, "points_per_s": B * N / wall,
+            "kernels": kern, "kernel_ms_sum": sum(ms) / iters,
+            "mlp": {"algorithmic_GFLOP": {k: v / 1e9 for k, v in fl.items()}, "total_GFLOP": total_fl / 1e9,
+                    "ms": mlp_ms, "TFLOP_per_s": total_fl / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None,
+                    "peak_TFLOP_per_s": PEAK,
+                    "frac_of_fp32_mfma_peak": total_fl / (mlp_ms * 1e-3) / 1e12 / PEAK if mlp_ms else None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=16)
@@ -54,44 +95,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--unfused", action="store_true", help="force the per-operator composition")
     a = ap.parse_args()
-    dev = torch.device("cuda", 0)
-    torch.manual_seed(0)
-    model = Point2NetSA(6, 64).eval().to(dev)
-    if a.unfused:
-        model.fused = False
-    x = torch.from_numpy(make_batch(a.B, a.N, seed=5)).to(dev)
-    L = _lib.lib()
-    with torch.no_grad():
-        for _ in range(3):
-            y = model(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.iters):
-            y = model(x)
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / a.iters
-        L.p2n_profile_select(-1)
-        L.p2n_profile_enable(1)
-        for _ in range(a.iters):
-            model(x)
-        ms = (ctypes.c_float * 32)()
-        cnt = (ctypes.c_int * 32)()
-        L.p2n_profile_collect(32, ms, cnt)
-        L.p2n_profile_enable(0)
-    assert bool(torch.isfinite(y).all())
-    fl = level_flops(model, a.B, a.N)
-    kern = {KNAMES.get(i, str(i)): {"ms_per_forward": ms[i] / a.iters, "launches_per_forward": cnt[i] / a.iters}
-            for i in range(32) if cnt[i]}
-    mlp_ms = sum(ms[i] for i in (14, 16, 17)) / a.iters
-    total_fl = sum(fl.values())
-    out = {"metric": "Point2NetSA eval forward (FPS+ball-query+MLP+3-NN), B=%d x N=%d" % (a.B, a.N),
-           "path": "unfused operators" if a.unfused else "fused levels",
-           "ms_per_forward_wall": 1e3 * wall, "points_per_s": a.B * a.N / wall,
-           "kernels": kern, "kernel_ms_sum": sum(ms) / a.iters,
-           "mlp": {"algorithmic_GFLOP": {k: v / 1e9 for k, v in fl.items()}, "total_GFLOP": total_fl / 1e9,
-                   "ms": mlp_ms, "TFLOP_per_s": total_fl / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None,
-                   "frac_of_fp32_mfma_peak": total_fl / (mlp_ms * 1e-3) / 1e12 / PEAK if mlp_ms else None}}
-    print(json.dumps(out))
+    print(json.dumps(run(a.B, a.N, a.iters, a.unfused)))
 
 
 if __name__ == "__main__":
