@@ -33,6 +33,122 @@ def predict(model, points, colors=None, eps: float = 0.1, min_samples: int = 50,
     return {"instance_labels": labels, "embeddings": emb, "num_instances": num, "centroid": centroid, "scale": scale}
 
 
+@torch.no_grad()
+def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap: bool = True):
+    """predict() over a sequence of scenes [(points, colors | None), ...] as a three-stage pipeline on one
+    GPU: while scene i runs normalise -> forward -> cluster on the compute stream, scene i+1's arrays are
+    already being uploaded from pinned staging buffers on a second stream, and scene i-1's labels and
+    embeddings leave through pinned buffers on a third (reference inference.py:168-176 does upload, forward,
+    download and clustering one after the other on one stream).  Yields the same dict per scene as predict().
+    overlap=False runs the scenes one by one through predict() (the comparison tools/bench_inference.py
+    reports)."""
+    if model.training:
+        raise RuntimeError("predict_many: call model.eval() first (reference inference.py:73)")
+    scenes = list(scenes)
+    if not overlap:
+        for pts, col in scenes:
+            yield predict(model, pts, col, eps=eps, min_samples=min_samples)
+        return
+    dev = next(model.parameters()).device
+    main = torch.cuda.current_stream(dev)
+    up, down = _side_streams(dev)
+
+    # Pinned staging is allocated once, before the pipeline starts: a fresh pinned allocation waits for the
+    # busy GPU (hipHostMalloc synchronises with the device) and would serialise the pipeline.  Uploads use two
+    # slots sized for the largest scene; a slot is rewritten only after its previous upload has completed.
+    nmax = max(len(p) for p, _ in scenes) if scenes else 0
+    up_ring = [(torch.empty((nmax, 3), dtype=torch.float64, pin_memory=True),
+                torch.empty((nmax, 3), dtype=torch.float64, pin_memory=True), [None]) for _ in range(min(2, len(scenes)))]
+
+    def stage(k):
+        pts, col = scenes[k]
+        p_h, c_h, last = up_ring[k % 2]
+        if last[0] is not None:
+            last[0].synchronize()
+        n = len(pts)
+        p_h[:n].copy_(torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)))
+        if col is not None:
+            c_h[:n].copy_(torch.from_numpy(np.ascontiguousarray(col, dtype=np.float64)))
+        with torch.cuda.stream(up):
+            p = p_h[:n].to(dev, non_blocking=True)
+            c = c_h[:n].to(dev, non_blocking=True) if col is not None else None
+            ev = torch.cuda.Event()
+            ev.record(up)
+        last[0] = ev
+        return p, c, ev
+
+    # Results leave through a ring of three pinned slots sized for the largest scene and are copied out into
+    # ordinary arrays when yielded: a fresh pinned allocation per scene would wait for the busy GPU
+    # (hipHostMalloc synchronises with the device) and serialise the pipeline.
+    E = model.embedding_dim
+    ring = [(torch.empty(nmax, dtype=torch.int64, pin_memory=True), torch.empty((nmax, E), dtype=torch.float32, pin_memory=True),
+             torch.empty(4, dtype=torch.float64, pin_memory=True), torch.empty(1, dtype=torch.int64, pin_memory=True))
+            for _ in range(min(3, len(scenes)))]
+
+    def finish(job):
+        slot, n, ev = job
+        labels_h, emb_h, cs_h, num_h = ring[slot]
+        ev.synchronize()
+        cs = cs_h.numpy()
+        return {"instance_labels": labels_h[:n].numpy().copy(), "embeddings": emb_h[:n].numpy().copy(),
+                "num_instances": int(num_h[0]) - 1, "centroid": cs[:3].copy(), "scale": np.float64(cs[3])}
+
+    pending = None
+    nxt = stage(0) if scenes else None
+    for i in range(len(scenes)):
+        p, c, ev = nxt
+        main.wait_event(ev)
+        for t in (p, c):
+            if t is not None:
+                t.record_stream(main)
+        if i + 1 < len(scenes):
+            nxt = stage(i + 1)                               # upload of scene i+1 beside the compute of scene i
+        feat, cs = preprocess_point_cloud(p, c, sync=False)
+        emb = model(feat)[0]
+        labels = cluster_embeddings(emb, eps=eps, min_samples=min_samples)
+        num = _count_labels(labels)
+        n = labels.shape[0]
+        done = torch.cuda.Event()
+        done.record(main)
+        labels_h, emb_h, cs_h, num_h = ring[i % 3]
+        with torch.cuda.stream(down):                        # results leave while scene i+1 computes
+            down.wait_event(done)
+            labels_h[:n].copy_(labels, non_blocking=True)
+            emb_h[:n].copy_(emb, non_blocking=True)
+            cs_h.copy_(cs, non_blocking=True)
+            num_h.copy_(num.reshape(1), non_blocking=True)
+            for t in (labels, emb, cs, num):
+                t.record_stream(down)
+            out_ev = torch.cuda.Event()
+            out_ev.record(down)
+        if pending is not None:
+            yield finish(pending)
+        pending = (i % 3, n, out_ev)
+    if pending is not None:
+        yield finish(pending)
+
+
+_streams = {}
+
+
+def _side_streams(dev: torch.device):
+    """The upload and download streams of a device, created once: the caching allocator keeps a pool per
+    stream, so fresh streams per call would pay hipMalloc for every staging tensor again."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _streams:
+        _streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _streams[key]
+
+
+def _count_labels(labels: torch.Tensor) -> torch.Tensor:
+    """number of distinct labels as a device scalar (no host synchronisation): labels are 0 (noise) or
+    1..K without gaps (reference inference.py:131-140 renumbers them), so it is max + 1 when a 0 occurs and
+    max otherwise -- the quantity the reference reports as len(np.unique(labels))."""
+    mx = labels.max().to(torch.int64)
+    has0 = (labels == 0).any().to(torch.int64)
+    return mx + has0
+
+
 class PointCloudInference:
     """Same constructor and methods as the reference class (reference inference.py:43-219), with the
     compute on libp2n_hip.so.  The device must be a GPU: the reference silently falls back to the CPU

@@ -24,11 +24,12 @@ def _f64_device(a, name):
     return a
 
 
-def preprocess_point_cloud(points, colors=None):
+def preprocess_point_cloud(points, colors=None, sync: bool = True):
     """points (N,3), colors (N,3) or None -> (features (1,N,6) float32 GPU tensor, centroid (3,)
     float64 numpy, scale float64): the reference's three return values, bit-identical to its
     numpy float64 evaluation.  The reference returns a CPU tensor that its caller moves to the
-    device (inference.py:169); here it is already there."""
+    device (inference.py:169); here it is already there.  sync=False returns (features, cs) with
+    cs = {cx, cy, cz, scale} as a float64 GPU tensor and does not wait for the device (pipelines)."""
     p = _f64_device(points, "points")
     c = _f64_device(colors, "colors")
     n = p.size(0)
@@ -44,5 +45,7 @@ def preprocess_point_cloud(points, colors=None):
         _lib.check(L.p2n_preprocess_points(p.data_ptr(), c.data_ptr() if c is not None else None, n, feat.data_ptr(),
                                            cs.data_ptr(), ws.data_ptr(), ws.numel(), _rt.stream_handle(p.device)),
                    "p2n_preprocess_points")
+    if not sync:
+        return feat, cs
     h = cs.cpu().numpy()
     return feat, h[:3].copy(), np.float64(h[3])

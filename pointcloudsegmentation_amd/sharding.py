@@ -27,9 +27,34 @@ def infer_sharded(model: torch.nn.Module, scenes: Sequence[torch.Tensor], rank: 
     rank's results through torch.distributed (gloo or nccl) and the others get {}."""
     dev = next(model.parameters()).device
     mine = {}
-    for i in shard_indices(len(scenes), rank, world):
-        x = scenes[i].to(dev, non_blocking=True).unsqueeze(0)
-        mine[i] = model(x)[0]
+    ids = shard_indices(len(scenes), rank, world)
+    if dev.type != "cuda":
+        for i in ids:
+            mine[i] = model(scenes[i].to(dev).unsqueeze(0))[0]
+    else:
+        # scene i+1 is uploaded from a pinned staging buffer on a side stream while scene i is computed
+        main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+
+        def stage(i):
+            with torch.cuda.stream(side):
+                src = scenes[i]
+                if not src.is_cuda:
+                    pinned = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                    pinned.copy_(src)
+                    src = pinned
+                x = src.to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return x, ev
+
+        nxt = stage(ids[0]) if ids else None
+        for k, i in enumerate(ids):
+            x, ev = nxt
+            main.wait_event(ev)
+            x.record_stream(main)
+            if k + 1 < len(ids):
+                nxt = stage(ids[k + 1])
+            mine[i] = model(x.unsqueeze(0))[0]
     if not gather or world == 1:
         return mine
     import torch.distributed as dist

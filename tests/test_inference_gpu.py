@@ -70,3 +70,31 @@ def test_point_cloud_inference_class_file_to_file(ref_weights, tmp_path):
     np.testing.assert_array_equal(inf.cluster_embeddings(res["embeddings"], 0.1, 20), want["instance_labels"])
     with pytest.raises(RuntimeError):
         PointCloudInference(str(tmp_path / "ckpt.pth"), str(tmp_path / "cfg.yaml"), device="cpu")
+
+
+def test_predict_many_pipeline_matches_predict(ref_weights):
+    """The three-stream pipeline (upload of scene i+1 beside the compute of scene i, results leaving on a
+    third stream) must return exactly what predict() returns scene by scene: same labels, bit-identical
+    embeddings, centroid, scale, instance count -- on ragged scene sizes, with and without colours."""
+    from pointcloudsegmentation_amd.inference import predict, predict_many
+    from pointcloudsegmentation_amd.point2net import Point2Net
+    rng = np.random.default_rng(9)
+    m = Point2Net(feature_dim=6, embedding_dim=64)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref_weights.items()}, strict=True)
+    m = m.cuda().eval()
+    scenes = []
+    for n in (5000, 1200, 9001, 300, 4096):
+        pts = rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])
+        col = rng.integers(0, 256, (n, 3)).astype(np.float64) if n != 300 else None
+        scenes.append((pts, col))
+    for overlap in (True, False):
+        got = list(predict_many(m, scenes, eps=0.1, min_samples=20, overlap=overlap))
+        assert len(got) == len(scenes)
+        for (pts, col), g in zip(scenes, got):
+            w = predict(m, pts, col, eps=0.1, min_samples=20)
+            np.testing.assert_array_equal(g["instance_labels"], w["instance_labels"])
+            np.testing.assert_array_equal(g["embeddings"], w["embeddings"])
+            np.testing.assert_array_equal(g["centroid"], w["centroid"])
+            assert g["scale"] == w["scale"] and g["num_instances"] == w["num_instances"]
+            assert g["instance_labels"].dtype == np.int64 and g["embeddings"].dtype == np.float32
+    assert list(predict_many(m, [])) == []

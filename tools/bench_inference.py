@@ -47,6 +47,26 @@ with torch.no_grad():
 out["cluster_ms_model_embeddings"], _ = timed(lambda: cluster_embeddings(emb[0]), a.steps)
 syn = torch.from_numpy(make_embeddings(a.n, 64, 11)).cuda()
 out["cluster_ms_33_cluster_embeddings"], _ = timed(lambda: cluster_embeddings(syn), a.steps)
+# stream of scenes (BASELINE configs[2]: 40k-150k points): ms per scene one after the other vs pipelined
+# (upload of scene i+1 and download of scene i-1 beside the compute of scene i)
+from pointcloudsegmentation_amd.inference import predict_many
+out["scene_stream"] = {}
+for n_s in (40000, 80000, 150000):
+    sc = []
+    for k in range(6):
+        r2 = np.random.default_rng(100 + k)
+        sc.append((r2.uniform(0, 1, (n_s, 3)) * np.array([8.0, 6.0, 3.0]), r2.integers(0, 256, (n_s, 3)).astype(np.float64)))
+    row = {}
+    for mode, ov in (("serial", False), ("pipelined", True)):
+        for _ in range(2):      # the caching allocators (device blocks per stream, pinned blocks) reach their steady state
+            list(predict_many(m, sc, overlap=ov))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res_s = list(predict_many(m, sc, overlap=ov))
+        torch.cuda.synchronize()
+        row[mode + "_ms_per_scene"] = 1e3 * (time.perf_counter() - t0) / len(sc)
+    row["speedup"] = row["serial_ms_per_scene"] / row["pipelined_ms_per_scene"]
+    out["scene_stream"][str(n_s)] = row
 if not a.no_cpu:
     mc = Point2Net(feature_dim=6, embedding_dim=64)
     mc.load_state_dict(m.state_dict())
