@@ -23,7 +23,7 @@
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define BN_EPS 1e-5
 
-enum { LD_X = 0, LD_BNRELU = 1, LD_BNBWD = 2, LD_EMBGRAD = 3 };
+enum { LD_X = 0, LD_BNRELU = 1, LD_BNBWD = 2, LD_EMBGRAD = 3, LD_PLAIN = 4 };
 
 // ---------------------------------------------------------------- weight image
 // Fragment f = (kt*CT + ct)*4 + g  (k-tile major: the order the layer kernel consumes them):
@@ -51,6 +51,7 @@ struct LayerArgs {
     const float *bias_cloud;  // [B][rows] added on top, may be NULL (layer 6: W6b.g)
     const float *tab;         // per-k constants: BNRELU {s,t}[K]; BNBWD {s,t,A1,A2,A3}[K]
     float *out;               // (rows,Ppad) channel-major, or (P,ldo) point-major when OUT_PM
+    float *dz_out;            // LD_BNBWD: if set (= in0), dz replaces da in place, so that the weight-gradient kernel reads ONE tensor
     int K, KT, rows, P, Ppad, N, ld;   // KT = ceil(K/32); ld: F for LD_X, E for LD_EMBGRAD / OUT_PM
 };
 
@@ -124,6 +125,17 @@ __device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool 
     return out;
 }
 
+// dz of k-tile kt back over da (same rows, this lane's column): every element was read by this lane only
+__device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg, int h, const f32x16 &v) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int k0 = 32 * kt + 8 * g + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < A.K) A.dz_out[(long)(k0 + j) * A.Ppad + pg] = v[4 * g + j];
+    }
+}
+
 // One wave = 32 points.  All CT output tiles are live accumulators; the reduction runs k-tile
 // by k-tile: while the CT*16 MFMAs of tile kt execute, the operands of tile kt+1 are already
 // in flight (fetched raw, transformed after the MFMAs), and the weights of the next chunk land
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
         for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
     p2n_dma_barrier();   // tab visible (and chunk 0 landed)
     f32x16 cur = tl_transform<MODE>(A, 0, valid, h, tab, KP, r0, r1);
+    if (MODE == LD_BNBWD && A.dz_out) tl_store_dz(A, 0, pg, h, cur);
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         if (kt % KPC == 0) {
@@ -173,7 +186,10 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA32(w[ct][j], cur[4 * g + j], acc[ct]);
         }
-        if (kt + 1 < KT) cur = tl_transform<MODE>(A, kt + 1, valid, h, tab, KP, r0, r1);
+        if (kt + 1 < KT) {
+            cur = tl_transform<MODE>(A, kt + 1, valid, h, tab, KP, r0, r1);
+            if (MODE == LD_BNBWD && A.dz_out) tl_store_dz(A, kt + 1, pg, h, cur);
+        }
     }
     const int cloud = valid ? (int)(pg / A.N) : 0;
 #pragma unroll
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
 
 // ---------------------------------------------------------------- wgrad: dW = dz . a^T over points
 struct WgArgs {
-    const float *a0;    // A side: LD_BNBWD: da (rows,Ppad); LD_EMBGRAD: gemb (P,E)
+    const float *a0;    // A side: LD_BNBWD: da (rows,Ppad); LD_PLAIN: dz (rows,Ppad); LD_EMBGRAD: gemb (P,E)
     const float *a1;    // A side: z (rows,Ppad)
     const float *atab;  // {s,t,A1,A2,A3}[rows]
     const float *b0;    // B side: LD_BNRELU: z_prev (cols,Ppad); LD_X: x (P,F)
@@ -239,7 +255,7 @@ template <int MODE>
 __device__ __forceinline__ void wgrad_fetch(WgStage<MODE> &st, const float *__restrict__ s0, const float *__restrict__ s1,
                                             int row0, int nrows, long p0, long pend, int Ppad, int ld) {
     const int t = threadIdx.x;
-    if (MODE == LD_BNBWD || MODE == LD_BNRELU) {
+    if (MODE == LD_BNBWD || MODE == LD_BNRELU || MODE == LD_PLAIN) {
         const int seg = (t & 3) * 16;
         const int row = row0 + (t >> 2);
 #pragma unroll
@@ -267,12 +283,12 @@ template <int MODE>
 __device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__restrict__ dst, const float *__restrict__ tab,
                                            int row0, int nrows, int ntab, long p0, long pend) {
     const int t = threadIdx.x;
-    if (MODE == LD_BNBWD || MODE == LD_BNRELU) {
+    if (MODE == LD_BNBWD || MODE == LD_BNRELU || MODE == LD_PLAIN) {
         const int r = t >> 2, seg = (t & 3) * 16;
         const int row = row0 + r;
         const bool rok = row < nrows;
         float c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-        if (rok) {
+        if (rok && MODE != LD_PLAIN) {
             c0 = tab[row]; c1 = tab[ntab + row];
             if (MODE == LD_BNBWD) { c2 = tab[2 * ntab + row]; c3 = tab[3 * ntab + row]; c4 = tab[4 * ntab + row]; }
         }
@@ -287,6 +303,8 @@ __device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__res
                         const float z = st.v1[i][j];
                         const float dy = fmaf(z, c0, c1) > 0.f ? st.v0[i][j] : 0.f;
                         o[j] = (p + j < pend) ? fmaf(c4, z, fmaf(c2, dy, c3)) : 0.f;
+                    } else if (MODE == LD_PLAIN) {
+                        o[j] = (p + j < pend) ? st.v0[i][j] : 0.f;
                     } else {
                         o[j] = (p + j < pend) ? fmaxf(fmaf(st.v0[i][j], c0, c1), 0.f) : 0.f;
                     }
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(256) void p2n_wgrad_kernel(WgArgs A) {
 //   ST_FWD     sum (z - pivot), sum (z - pivot)^2          pivot = z[row][0]
 //   ST_BWD     sum dy, sum dy*zhat                          dy = da masked by relu, zhat = (z-mean)*rstd
 //   ST_DZCLOUD sum over one cloud of dz (slice = cloud)      -> part[(cloud*rows+row)] (single value)
-enum { ST_FWD = 0, ST_BWD = 1, ST_DZCLOUD = 2 };
+enum { ST_FWD = 0, ST_BWD = 1, ST_DZCLOUD = 2, ST_PLAINCLOUD = 3 };   // ST_PLAINCLOUD: per-cloud sum of da (holding dz)
 struct StatArgs {
     const float *z, *da;
     const float *tab;    // ST_BWD: {s,t,mean,rstd}[rows]; ST_DZCLOUD: {s,t,A1,A2,A3}[rows]
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(256) void p2n_row_stats_kernel(StatArgs A) {
     __shared__ float sh[4];
     const int row = blockIdx.x, s = blockIdx.y;
     long p0, p1;
-    if (MODE == ST_DZCLOUD) { p0 = (long)s * A.N; p1 = p0 + A.N; }
+    if (MODE == ST_DZCLOUD || MODE == ST_PLAINCLOUD) { p0 = (long)s * A.N; p1 = p0 + A.N; }
     else {
         const long len = ((long)A.P + A.S - 1) / A.S;
         p0 = (long)s * len; p1 = p0 + len;
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(256) void p2n_row_stats_kernel(StatArgs A) {
     const float *da = A.da ? A.da + (long)row * A.Ppad : nullptr;
     float sc = 0.f, sf = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, pivot = 0.f;
     if (MODE == ST_FWD) pivot = z[0];
-    else {
+    else if (MODE != ST_PLAINCLOUD) {
         sc = A.tab[row]; sf = A.tab[A.rows + row]; c2 = A.tab[2 * A.rows + row]; c3 = A.tab[3 * A.rows + row];
         if (MODE == ST_DZCLOUD) c4 = A.tab[4 * A.rows + row];
     }
@@ -434,9 +452,11 @@ __global__ __launch_bounds__(256) void p2n_row_stats_kernel(StatArgs A) {
         } else if (MODE == ST_BWD) {   // c2 = mean, c3 = rstd
             const float dy = fmaf(zz, sc, sf) > 0.f ? dd : 0.f;
             ud += (double)dy; vd += (double)(dy * ((zz - c2) * c3));
-        } else {                        // c2,c3,c4 = A1,A2,A3
+        } else if (MODE == ST_DZCLOUD) {   // c2,c3,c4 = A1,A2,A3
             const float dy = fmaf(zz, sc, sf) > 0.f ? dd : 0.f;
             ud += (double)fmaf(c4, zz, fmaf(c2, dy, c3));
+        } else {
+            ud += (double)dd;
         }
     };
     // 16-byte loads over the aligned middle of [p0,p1), scalar head and tail (rows start 512-byte aligned)
@@ -453,9 +473,9 @@ __global__ __launch_bounds__(256) void p2n_row_stats_kernel(StatArgs A) {
     for (long p = q1 + threadIdx.x; p < p1; p += 256) one(z[p], MODE == ST_FWD ? 0.f : da[p]);
     float u = (float)ud, v = (float)vd;
     u = block_sum_256(u, sh);
-    if (MODE != ST_DZCLOUD) v = block_sum_256(v, sh);
+    if (MODE != ST_DZCLOUD && MODE != ST_PLAINCLOUD) v = block_sum_256(v, sh);
     if (threadIdx.x == 0) {
-        if (MODE == ST_DZCLOUD) A.part[(long)s * A.rows + row] = u;
+        if (MODE == ST_DZCLOUD || MODE == ST_PLAINCLOUD) A.part[(long)s * A.rows + row] = u;
         else { A.part[((long)row * A.S + s) * 2] = u; A.part[((long)row * A.S + s) * 2 + 1] = v; }
     }
 }
@@ -904,34 +924,38 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
         hipLaunchKernelGGL(p2n_bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, s, n.part, C, STAT_S, n.P,
                            n.gamma[l], n.ftab[l], dgam[l], dbet[l], n.btab, n.mode, db[l]);
         P2N_CHECK_HIP(hipGetLastError());
-        // weight gradient
-        WgArgs w = {};
-        w.a0 = n.da[cur]; w.a1 = n.z[l]; w.atab = n.btab; w.dW = dW[l];
-        w.rows = C; w.ldw = n.cin[l]; w.P = n.P; w.Ppad = n.Ppad;
-        if (l == 0) { w.b0 = x; w.ld_b = F; w.cols = F; TRY((launch_wgrad<LD_BNBWD, LD_X>(w, s))); }
-        else {
-            w.b0 = n.z[l - 1]; w.btab = n.ftab[l - 1]; w.cols = (l == 6) ? 256 : n.cin[l];
-            TRY((launch_wgrad<LD_BNBWD, LD_BNRELU>(w, s)));
+        if (l == 0) {   // no data gradient below the first layer: its weight gradient forms dz in its own loader
+            WgArgs w = {};
+            w.a0 = n.da[cur]; w.a1 = n.z[0]; w.atab = n.btab; w.dW = dW[0];
+            w.rows = C; w.ldw = n.cin[0]; w.P = n.P; w.Ppad = n.Ppad;
+            w.b0 = x; w.ld_b = F; w.cols = F;
+            TRY((launch_wgrad<LD_BNBWD, LD_X>(w, s)));
+            break;
         }
+        // data gradient first: da_{l-1} = W_l^T . dz_l, and its loader leaves dz_l in place of da_l
+        const int rows = (l == 6) ? 256 : n.cin[l];
+        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, s));
+        LayerArgs a = {};
+        a.in0 = n.da[cur]; a.in1 = n.z[l]; a.tab = n.btab; a.wimg = n.wimg; a.K = C; a.rows = rows;
+        a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[cur ^ 1]; a.dz_out = n.da[cur];
+        TRY((launch_layer<LD_BNBWD, false>(a, s)));
+        // weight gradient from dz_l (one tensor, no transform on that side)
+        WgArgs w = {};
+        w.a0 = n.da[cur]; w.dW = dW[l];
+        w.rows = C; w.ldw = n.cin[l]; w.P = n.P; w.Ppad = n.Ppad;
+        w.b0 = n.z[l - 1]; w.btab = n.ftab[l - 1]; w.cols = (l == 6) ? 256 : n.cin[l];
+        TRY((launch_wgrad<LD_PLAIN, LD_BNRELU>(w, s)));
         if (l == 6) {
             // global branch: per-cloud sums of dz6 -> dW6[:,256:] and dg
             StatArgs sc = st;
-            sc.tab = n.btab; sc.part = n.dzsum6;
-            hipLaunchKernelGGL(p2n_row_stats_kernel<ST_DZCLOUD>, dim3(256, B), dim3(256), 0, s, sc);
+            sc.da = n.da[cur]; sc.part = n.dzsum6;
+            hipLaunchKernelGGL(p2n_row_stats_kernel<ST_PLAINCLOUD>, dim3(256, B), dim3(256), 0, s, sc);
             P2N_CHECK_HIP(hipGetLastError());
             hipLaunchKernelGGL(p2n_outer_sum_kernel, dim3(1, 256), dim3(256), 0, s, n.dzsum6, n.g, B, 256, 256, dW[6], 512, 256);
             P2N_CHECK_HIP(hipGetLastError());
             hipLaunchKernelGGL(p2n_small_gemv_kernel, dim3(4, B), dim3(256), 0, s, n.W[6], 512, 256, 1, n.dzsum6, 256, 256, n.dg);
             P2N_CHECK_HIP(hipGetLastError());
         }
-        if (l == 0) break;
-        // data gradient: da_{l-1} = W_l^T . dz_l
-        const int rows = (l == 6) ? 256 : n.cin[l];
-        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, s));
-        LayerArgs a = {};
-        a.in0 = n.da[cur]; a.in1 = n.z[l]; a.tab = n.btab; a.wimg = n.wimg; a.K = C; a.rows = rows;
-        a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[cur ^ 1];
-        TRY((launch_layer<LD_BNBWD, false>(a, s)));
         cur ^= 1;
         if (l == 6) {
             hipLaunchKernelGGL(p2n_maxpool_bwd_kernel, dim3((256 * B + 255) / 256), dim3(256), 0, s, n.da[cur], n.Ppad, N,
