@@ -11,13 +11,13 @@
 
 // Tuning overrides for the sweep tools (tools/fps_sweep.py, tools/sweep_gather.sh), read from the
 // environment once per process: 0 / unset = the built-in choice.
-struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault; };
+struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd; };
 static const P2nTuning &p2n_tuning() {
     static const P2nTuning t = [] {
         auto num = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
         return P2nTuning{num("P2N_FPS_G"), num("P2N_GL_CH"), num("P2N_GL_THREADS"), num("P2N_GL_SPLIT"),
                          getenv("P2N_GL_OFF") ? 1 : 0, num("P2N_FPS_T"), num("P2N_FPS_SPIN"),
-                         num("P2N_FPS_FAULT")};
+                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD")};
     }();
     return t;
 }
@@ -92,9 +92,10 @@ __device__ __forceinline__ void lds_max_u64(u64 *p, u64 v) {
 struct FpsArgs {
     const float *xyz;   // (B,N,3)
     int32_t *idx;       // (B,M)
-    u64 *slots;         // [clouds of this launch][M][G][4], zeroed per launch (G > 1 only)
+    u64 *slots;         // [clouds of this launch][M+1][G][4], zeroed per launch (G > 1 only); row M: the XCD census
     int *status;        // set to 1 when an exchange timed out (never cleared here)
     int N, M, G, chunk, start_idx, b0, spin_limit;
+    int xcd_mode, nb;   // xcd_mode: grid = 8*G*ceil(nb/8) blocks, a cloud's workgroups share blockIdx % 8 (one XCD under round-robin dealing)
     int fault_it;       // test hook (P2N_FPS_FAULT=k): the cloud's last workgroup skips its publish in iteration k; 0 = off
 };
 
@@ -105,7 +106,17 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
     __shared__ u64 wkey[3];
     __shared__ float bc[2][4];   // broadcast of the iteration's winner (G > 1)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int b = A.b0 + blockIdx.x / A.G, g = blockIdx.x % A.G;
+    int b, g;
+    if (A.xcd_mode) {
+        // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised): cloud c takes the blocks
+        // with blockIdx % 8 == c % 8, so that its cluster shares one L2 -- verified below before it is relied on.
+        const int r = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int cl = (q / A.G) * 8 + r;
+        if (cl >= A.nb) return;
+        b = A.b0 + cl; g = q % A.G;
+    } else {
+        b = A.b0 + blockIdx.x / A.G; g = blockIdx.x % A.G;
+    }
     const float *P = A.xyz + (long)b * A.N * 3;
     const int base = g * A.chunk;
     int nloc = A.N - base;
@@ -135,11 +146,41 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
     int cur = A.start_idx;
     float cx = P[(long)cur * 3 + 0], cy = P[(long)cur * 3 + 1], cz = P[(long)cur * 3 + 2];
     bool dead = false;
+    // XCD census: every workgroup of the cluster publishes the id of the XCD it runs on (write-through store,
+    // the form that is valid across XCDs) and reads everybody's.  Only if all agree may the per-iteration
+    // exchange use plain stores, which stay in that XCD's L2 where the polling loads (L1 bypassed) find them a
+    // few hundred cycles later; across XCDs a plain store would never become visible, so any disagreement (or
+    // any other placement than the expected one) keeps the write-through form.  Every workgroup reads the
+    // same ids, hence takes the same decision.
+    bool fast = false, census_dead = false;
+    if (A.G > 1 && A.xcd_mode) {
+        if (wave == 0) {
+            u64 *cs = A.slots + (((long)(b - A.b0) * (A.M + 1) + A.M) * A.G) * 4;
+            const unsigned myx = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 0xF;   // hwreg(HW_REG_XCC_ID, 0, 4)
+            if (lane == 0) __hip_atomic_store(cs + g * 4, (1ull << 32) | (u64)myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64 v = 1ull << 32 | myx;
+            int spins = 0;
+            bool ok;
+            for (;;) {
+                if (lane < A.G) v = __hip_atomic_load(cs + lane * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = __all(lane >= A.G || v != 0ull);
+                if (ok || ++spins > A.spin_limit) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool same = __all(lane >= A.G || (unsigned)v == myx);
+            if (lane == 0) bc[0][0] = __int_as_float(ok ? (same ? 1 : 0) : -1);
+        }
+        __syncthreads();
+        const int verdict = __float_as_int(bc[0][0]);
+        __syncthreads();
+        fast = verdict == 1;
+        if (verdict < 0) dead = census_dead = true;
+    }
     const unsigned inv0 = 0xFFFFFFFFu - (unsigned)(base + t);
     int kb = 0;   // it % 3
 
     int it = 0;
-    for (; it < A.M; ++it) {
+    for (; it < A.M && !dead; ++it) {
         if (g == 0 && t == 0) A.idx[(long)b * A.M + it] = cur;
         if (it + 1 == A.M) break;
         // ---- update running minima (v_min_f32 as the instruction: fminf() would canonicalise its
@@ -189,7 +230,7 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
         } else {
             const int buf = it & 1;
             if (wave == 0) {
-                u64 *slot = A.slots + (((long)(b - A.b0) * A.M + it) * A.G) * 4;
+                u64 *slot = A.slots + (((long)(b - A.b0) * (A.M + 1) + it) * A.G) * 4;
                 if (lane < 4 && !(A.fault_it > 0 && it == A.fault_it && g == A.G - 1)) {
                     u64 payload = k;
                     if (lane > 0) {
@@ -198,7 +239,12 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
                         const float c = !real ? 0.f : (LDSXYZ ? lxyz[(li - base) * 3 + lane - 1] : P[(long)li * 3 + lane - 1]);
                         payload = ((k & 0xFFFFFFFFull) << 32) | (u64)__float_as_uint(c);
                     }
-                    __hip_atomic_store(slot + g * 4 + lane, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (fast) {   // same XCD: a plain store, served to the pollers from the shared L2
+                        u64 *dst = slot + g * 4 + lane;
+                        asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(payload) : "memory");
+                    } else {
+                        __hip_atomic_store(slot + g * 4 + lane, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 u64 v0 = 0, v1 = 0, v2 = 0, v3 = 0;
                 int spins = 0;
@@ -252,7 +298,7 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
         // unwritten -- the rest of the row repeats the start point, so that no consumer gathers out of bounds
         if (t == 0) atomicExch(A.status, 1);
         if (g == 0)
-            for (int i = it + 1 + t; i < A.M; i += T) A.idx[(long)b * A.M + i] = A.start_idx;
+            for (int i = (census_dead ? 0 : it + 1) + t; i < A.M; i += T) A.idx[(long)b * A.M + i] = A.start_idx;
     }
 }
 
@@ -289,6 +335,10 @@ static FpsPlan fps_plan(int B, int N) {
         if (G > 1) {
             G = (N + 4095) / 4096;
             if (G > gmax) G = gmax;
+            // a cluster that fits one XCD (ncu/8 CUs) exchanges through that XCD's L2 (see the kernel): worth
+            // fatter workgroups when the cloud would otherwise spill over a second XCD
+            const int per_xcd = ncu / 8;
+            if (G > per_xcd && B <= 8 && (N + per_xcd - 1) / per_xcd <= FPS_LDS_POINTS && gmin256 <= per_xcd) G = per_xcd;
         }
         p.T = 256;
     } else {
@@ -326,7 +376,7 @@ extern "C" size_t p2n_fps_workspace_bytes(int B, int N, int M) {
     // slots of the largest sub-batch: at most 64 workgroups per cloud, 32 bytes each per sample
     const FpsPlan p = fps_plan(1, N);
     const int gmax = p.G > 1 ? 64 : 1;
-    return 16 + (gmax > 1 ? sizeof(u64) * 4 * (size_t)B * M * gmax : 0);
+    return 16 + (gmax > 1 ? sizeof(u64) * 4 * (size_t)B * (M + 1) * gmax : 0);
 }
 
 template <int T, int PPT, bool LDSXYZ>
@@ -338,7 +388,8 @@ static hipError_t fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     const int ps = p2n_prof_begin(P2N_K_FPS, s);
-    hipLaunchKernelGGL((p2n_fps_kernel<T, PPT, LDSXYZ>), dim3(nb * a.G), dim3(T), lds, s, a);
+    const unsigned grid = a.xcd_mode ? 8u * a.G * ((nb + 7) / 8) : (unsigned)(nb * a.G);
+    hipLaunchKernelGGL((p2n_fps_kernel<T, PPT, LDSXYZ>), dim3(grid), dim3(T), lds, s, a);
     p2n_prof_end(ps, s);
     return hipGetLastError();
 }
@@ -377,10 +428,13 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         P2N_REQUIRE(p.G >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 64 * 1024 * 20);
         FpsArgs a;
         a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault;
+        a.nb = nb;
+        // one XCD per cloud when its cluster and the other clouds sharing that XCD fit the XCD's 32 CUs
+        a.xcd_mode = p.G > 1 && p.G * ((nb + 7) / 8) <= ncu / 8 && !p2n_tuning().fps_noxcd;
         a.slots = (u64 *)((char *)workspace + 16);
         a.N = N; a.M = M; a.G = p.G; a.chunk = (N + p.G - 1) / p.G; a.start_idx = start_idx; a.b0 = done;
         if (p.G > 1)   // launches run in stream order, so they can share the slot region
-            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 16, 0, sizeof(u64) * 4 * (size_t)nb * M * p.G, stream));
+            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 16, 0, sizeof(u64) * 4 * (size_t)nb * (M + 1) * p.G, stream));
         hipError_t e = hipErrorInvalidValue;
         if (p.T == 256) {
             switch (p.ppt) {
