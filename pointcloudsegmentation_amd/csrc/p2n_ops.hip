@@ -106,6 +106,9 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
     __shared__ u64 wkey[3];
     __shared__ float bc[2][4];   // broadcast of the iteration's winner (G > 1)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // every iteration is a chain of dependent steps on a handful of CUs: waves of other kernels that share those
+    // CUs (the level kernels run beside the FPS chain) must not take its issue slots
+    __builtin_amdgcn_s_setprio(3);
     int b, g;
     if (A.xcd_mode) {
         // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised): cloud c takes the blocks

@@ -206,7 +206,7 @@ class SetAbstraction(nn.Module):
     def fused_supported(self) -> bool:
         return self.nsample == 32 and len(self.mlp.net) == 9 and self._image.supported([self.mlp], 3)
 
-    def forward_rows(self, xyz, rows, ld, feat_off, C):
+    def forward_rows(self, xyz, rows, ld, feat_off, C, geometry=None):
         """The level on point-major rows, one fused kernel (p2n_sa_level): xyz (B,N,3) contiguous;
         rows (B,N,ld) whose first three columns are the coordinates when feat_off > 0 (level 1 reads the
         input tensor itself: x = [xyz | features]) -- otherwise rows are the C features alone and the
@@ -215,9 +215,12 @@ class SetAbstraction(nn.Module):
         B, N, _ = xyz.shape
         M = max(1, N // self.npoint_div)
         dev = xyz.device
-        fidx = ops.farthest_point_sample(xyz, M)
-        new_xyz = gather_xyz(xyz, 3, fidx)
-        gidx = ops.ball_query(xyz, new_xyz, self.radius, self.nsample)
+        if geometry is None:
+            fidx = ops.farthest_point_sample(xyz, M)
+            new_xyz = gather_xyz(xyz, 3, fidx)
+            gidx = ops.ball_query(xyz, new_xyz, self.radius, self.nsample)
+        else:                                           # (new_xyz, gidx) computed ahead on the geometry streams
+            new_xyz, gidx = geometry
         packed = self._image.get([self.mlp], 3, dev)
         mlp = self._image.dims[1:]
         out = torch.empty((B, M, mlp[-1]), dtype=torch.float32, device=dev)
@@ -275,7 +278,8 @@ class FeaturePropagation(nn.Module):
             return len(self.mlp.net) == 6 and self._image.supported([self.mlp], C1)
         return len(self.mlp.net) == 6 and len(head.net) == 4 and self._image_head.supported([self.mlp, head], C1)
 
-    def forward_rows(self, xyz1, xyz2, skip, ld_skip, skip_off, C1, feat2, head: Optional["SharedMLP"] = None):
+    def forward_rows(self, xyz1, xyz2, skip, ld_skip, skip_off, C1, feat2, head: Optional["SharedMLP"] = None,
+                     neighbours=None):
         """The level on point-major rows, one fused kernel (p2n_fp_level): xyz1 (B,n,3) fine points, xyz2
         (B,m,3) coarse points, skip rows (B,n,ld_skip) whose columns skip_off..skip_off+C1-1 are the fine
         points' own features (None with C1 = 0), feat2 (B,m,C2) coarse features.  With `head` the embedding
@@ -284,7 +288,7 @@ class FeaturePropagation(nn.Module):
         B, n, _ = xyz1.shape
         m, C2 = feat2.shape[1], feat2.shape[2]
         dev = xyz1.device
-        _, idx3, w3 = ops.three_nn(xyz1, xyz2)
+        idx3, w3 = neighbours if neighbours is not None else ops.three_nn(xyz1, xyz2)[1:]
         image, mlps = (self._image, [self.mlp]) if head is None else (self._image_head, [self.mlp, head])
         packed = image.get(mlps, C1, dev)
         mlp = image.dims[1:]
@@ -320,6 +324,7 @@ class Point2NetSA(nn.Module):
         c = feature_dim - 3
         self.feature_dim, self.embedding_dim = feature_dim, embedding_dim
         self.fused = True        # GPU eval: fused level kernels (p2n_sa_level / p2n_fp_level); False = per-operator composition
+        self.overlap_geometry = True   # fused path: FPS chain / ball queries / three-NN on side streams beside the level kernels
         self.sa1 = SetAbstraction(4, radii[0], nsample, c, [32, 32, 64])
         self.sa2 = SetAbstraction(4, radii[1], nsample, 64, [64, 64, 128])
         self.sa3 = SetAbstraction(4, radii[2], nsample, 128, [128, 128, 256])
@@ -356,16 +361,84 @@ class Point2NetSA(nn.Module):
                 and self.fp1.fused_supported(c, self.head))
 
     def _forward_fused(self, x):
+        """Everything that depends on coordinates only -- the FPS chain (65 % of the forward, latency-bound on
+        16 of the 256 CUs), the ball queries and the three-NN searches -- runs on side streams beside the level
+        kernels: FPS of level l+1 starts as soon as level l's centroids exist, not after level l's MLP."""
         x = _rt.require_cuda_f32(x, "x")
         F = self.feature_dim
         c = F - 3
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
         xyz0 = x[:, :, :3].contiguous()
-        xyz1, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c)                     # level 1 reads x's rows in place
-        xyz2, f2 = self.sa2.forward_rows(xyz1, f1, f1.shape[2], 0, f1.shape[2])
-        xyz3, f3 = self.sa3.forward_rows(xyz2, f2, f2.shape[2], 0, f2.shape[2])
-        u2 = self.fp3.forward_rows(xyz2, xyz3, f2, f2.shape[2], 0, f2.shape[2], f3)
-        u1 = self.fp2.forward_rows(xyz1, xyz2, f1, f1.shape[2], 0, f1.shape[2], u2)
-        emb = self.fp1.forward_rows(xyz0, xyz1, x, F, 3, c, u1, head=self.head)   # (B,N,E)
+        if not self.overlap_geometry:
+            xyz1, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c)                     # level 1 reads x's rows in place
+            xyz2, f2 = self.sa2.forward_rows(xyz1, f1, f1.shape[2], 0, f1.shape[2])
+            xyz3, f3 = self.sa3.forward_rows(xyz2, f2, f2.shape[2], 0, f2.shape[2])
+            u2 = self.fp3.forward_rows(xyz2, xyz3, f2, f2.shape[2], 0, f2.shape[2], f3)
+            u1 = self.fp2.forward_rows(xyz1, xyz2, f1, f1.shape[2], 0, f1.shape[2], u2)
+            emb = self.fp1.forward_rows(xyz0, xyz1, x, F, 3, c, u1, head=self.head)   # (B,N,E)
+        else:
+            s_fps, s_search, s_nn = _geometry_streams(dev)
+            sas = (self.sa1, self.sa2, self.sa3)
+            start = torch.cuda.Event()
+            start.record(main)
+            for st in (s_fps, s_search, s_nn):
+                xyz0.record_stream(st)
+            xyz, cent = [xyz0], []
+            with torch.cuda.stream(s_fps):                   # fps1 -> fps2 -> fps3, nothing in between
+                s_fps.wait_event(start)
+                for sa in sas:
+                    M = max(1, xyz[-1].shape[1] // sa.npoint_div)
+                    nx = gather_xyz(xyz[-1], 3, ops.farthest_point_sample(xyz[-1], M))
+                    ev = torch.cuda.Event()
+                    ev.record(s_fps)
+                    xyz.append(nx)
+                    cent.append(ev)
+            with torch.cuda.stream(s_nn):                    # the largest search (fine points x level-1 centroids)
+                s_nn.wait_event(cent[0])
+                nn01 = ops.three_nn(xyz[0], xyz[1])[1:]
+                e_nn01 = torch.cuda.Event()
+                e_nn01.record(s_nn)
+            groups, e_ball = [], []
+            with torch.cuda.stream(s_search):
+                for l, sa in enumerate(sas):
+                    s_search.wait_event(cent[l])
+                    groups.append(ops.ball_query(xyz[l], xyz[l + 1], sa.radius, sa.nsample))
+                    ev = torch.cuda.Event()
+                    ev.record(s_search)
+                    e_ball.append(ev)
+                nn23 = ops.three_nn(xyz[2], xyz[3])[1:]
+                nn12 = ops.three_nn(xyz[1], xyz[2])[1:]
+                e_nn = torch.cuda.Event()
+                e_nn.record(s_search)
+            for t in xyz[1:] + groups + list(nn01) + list(nn12) + list(nn23):
+                t.record_stream(main)                        # allocated on a side stream, consumed on this one
+            xyz[1].record_stream(s_nn)
+            for t in xyz[1:]:
+                t.record_stream(s_search)
+            main.wait_event(e_ball[0])
+            _, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c, geometry=(xyz[1], groups[0]))
+            main.wait_event(e_ball[1])
+            _, f2 = self.sa2.forward_rows(xyz[1], f1, f1.shape[2], 0, f1.shape[2], geometry=(xyz[2], groups[1]))
+            main.wait_event(e_ball[2])
+            _, f3 = self.sa3.forward_rows(xyz[2], f2, f2.shape[2], 0, f2.shape[2], geometry=(xyz[3], groups[2]))
+            main.wait_event(e_nn)
+            u2 = self.fp3.forward_rows(xyz[2], xyz[3], f2, f2.shape[2], 0, f2.shape[2], f3, neighbours=nn23)
+            u1 = self.fp2.forward_rows(xyz[1], xyz[2], f1, f1.shape[2], 0, f1.shape[2], u2, neighbours=nn12)
+            main.wait_event(e_nn01)
+            emb = self.fp1.forward_rows(xyz0, xyz[1], x, F, 3, c, u1, head=self.head, neighbours=nn01)
         if ops.fps_needs_check(x.shape[0], x.shape[1]):
             ops.fps_check(x.device)      # clouds sampled by workgroup clusters: a timed-out exchange raises here
         return emb
+
+
+_geo_streams = {}
+
+
+def _geometry_streams(dev: torch.device):
+    """three side streams per device (FPS chain, ball queries + small three-NN searches, the large three-NN
+    search), created once: the caching allocator keeps a pool per stream"""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _geo_streams:
+        _geo_streams[key] = tuple(torch.cuda.Stream(device=dev) for _ in range(3))
+    return _geo_streams[key]

@@ -219,3 +219,30 @@ def test_point2net_sa_fused_vs_unfused_at_the_bench_shape():
         want = m(x)
     assert got.shape == (16, 8192, 64)
     assert_close_to_max(got.cpu().numpy(), want.cpu().numpy(), 5e-6, "fused vs per-operator Point2NetSA at 16 x 8192")
+
+
+def test_point2net_sa_geometry_streams_change_nothing():
+    """FPS chain / ball queries / three-NN on side streams vs everything on one stream: bit-identical output,
+    also when called repeatedly (stream and allocator reuse) and on a non-default current stream."""
+    from pointcloudsegmentation_amd.pointnet2 import Point2NetSA
+    from pointcloudsegmentation_amd.synth import make_batch
+    torch.manual_seed(6)
+    m = Point2NetSA(6, 64).eval()
+    _randomise_bn(m)
+    m = m.cuda()
+    xs = [torch.from_numpy(make_batch(b, n, seed=n)).cuda() for b, n in ((3, 4096), (1, 777), (5, 2048), (3, 4096))]
+    with torch.no_grad():
+        m.overlap_geometry = False
+        want = [m(x).clone() for x in xs]
+        m.overlap_geometry = True
+        for _ in range(3):
+            got = [m(x) for x in xs]
+            torch.cuda.synchronize()
+            for g, w in zip(got, want):
+                assert torch.equal(g, w)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            got = [m(x) for x in xs]
+        side.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)

@@ -47,12 +47,14 @@ def level_flops(model, B, N):
     return out
 
 
-def run(B=16, N=8192, iters=20, unfused=False):
+def run(B=16, N=8192, iters=20, unfused=False, serial=False):
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(0)
     model = Point2NetSA(6, 64).eval().to(dev)
     if unfused:
         model.fused = False
+    if serial:
+        model.overlap_geometry = False
     x = torch.from_numpy(make_batch(B, N, seed=5)).to(dev)
     L = _lib.lib()
     with torch.no_grad():
@@ -79,7 +81,7 @@ def run(B=16, N=8192, iters=20, unfused=False):
     mlp_ms = sum(ms[i] for i in (14, 16, 17)) / iters
     total_fl = sum(fl.values())
     return {"metric": "Point2NetSA eval forward (FPS+ball-query+MLP+3-NN), B=%d x N=%d" % (B, N),
-            "path": "per-operator composition" if unfused else "fused levels",
+            "path": "per-operator composition" if unfused else ("fused levels, one stream" if serial else "fused levels, geometry on side streams"),
             "ms_per_forward_wall": 1e3 * wall, "points_per_s": B * N / wall,
             "kernels": kern, "kernel_ms_sum": sum(ms) / iters,
             "mlp": {"algorithmic_GFLOP": {k: v / 1e9 for k, v in fl.items()}, "total_GFLOP": total_fl / 1e9,
@@ -94,8 +96,9 @@ def main():
     ap.add_argument("--N", type=int, default=8192)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--unfused", action="store_true", help="force the per-operator composition")
+    ap.add_argument("--serial", action="store_true", help="fused levels with everything on one stream")
     a = ap.parse_args()
-    print(json.dumps(run(a.B, a.N, a.iters, a.unfused)))
+    print(json.dumps(run(a.B, a.N, a.iters, a.unfused, a.serial)))
 
 
 if __name__ == "__main__":
