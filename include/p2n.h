@@ -115,6 +115,26 @@ int p2n_train_backward(const float *x, const float *gemb, int B, int N, int feat
                        const void *const *params_host, void *const *grads_host,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* Shared MLP of a hierarchical level in train() mode (no reference counterpart: the north star names
+ * set-abstraction / feature-propagation levels, the reference has none; semantics = torch's
+ * nn.Sequential(Conv1d(k=1), BatchNorm1d, ReLU, ...) in train() mode, parity unpinned by the reference and
+ * tested against that torch composition).  The matrix is channel-major over all P columns of the batch
+ * ((cloud, point) or (cloud, centroid, neighbour) flattened): x_cm (dims[0], Ppad), out_cm (dims[nl], Ppad),
+ * Ppad = P rounded up to 128; dims[0] <= 1024, dims[1..] <= 256, nl <= 8; last_plain != 0: the last layer is a
+ * Conv1d alone.  params_host: HOST array of 6 DEVICE pointers per layer (W, bias, bn.weight, bn.bias,
+ * running_mean, running_var; the last four NULL for a plain last layer); running statistics are updated in
+ * place (momentum in [0,1], unbiased variance, eps 1e-5).  The workspace keeps the pre-BatchNorm activations and
+ * must stay untouched until p2n_mlp_train_backward, which takes dout_cm = dL/d out_cm (OVERWRITTEN) and fills
+ * grads_host (HOST array of 4 DEVICE pointers per layer: dW, dbias, dgamma, dbeta; the last two NULL for a plain
+ * last layer) and dx_cm = dL/d x_cm (dims[0], Ppad), or skips the input gradient when dx_cm is NULL. */
+size_t p2n_mlp_train_workspace_bytes(long P, int nl, const int *dims, int last_plain);
+int p2n_mlp_train_forward(const float *x_cm, long P, int nl, const int *dims, int last_plain,
+                          const void *const *params_host, float momentum, float *out_cm,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int p2n_mlp_train_backward(const float *x_cm, float *dout_cm, long P, int nl, const int *dims, int last_plain,
+                           const void *const *params_host, void *const *grads_host, float *dx_cm,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* InstanceSegLoss (reference losses.py:332-373) = DiscriminativeLoss pull/push
  * (:375-452) + SmoothnessLoss (:454-489, brute-force kNN k+1 with column 0 dropped),
  * values AND gradient w.r.t. the embeddings in one call.

@@ -44,7 +44,7 @@ __global__ void p2n_pack_w_kernel(const float *__restrict__ W, int ldw, int col0
 
 // ---------------------------------------------------------------- layer GEMM (forward / dgrad)
 struct LayerArgs {
-    const float *in0;         // LD_X: x (P,F); LD_BNRELU: z_prev (K,Ppad); LD_BNBWD: da (K,Ppad); LD_EMBGRAD: gemb (P,E)
+    const float *in0;         // LD_X: x (P,F); LD_BNRELU: z_prev (K,Ppad); LD_BNBWD: da (K,Ppad); LD_EMBGRAD: gemb (P,E); LD_PLAIN: (K,Ppad) as is
     const float *in1;         // LD_BNBWD: z (K,Ppad)
     const float *wimg;        // [KT][CT][4][64][4]
     const float *bias;        // per output row, may be NULL
@@ -94,7 +94,7 @@ __device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bo
 template <int MODE>
 __device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool valid, int h, const float *tab, int KP,
                                                const f32x16 &r0, const f32x16 &r1) {
-    if (MODE == LD_X || MODE == LD_EMBGRAD) return r0;
+    if (MODE == LD_X || MODE == LD_EMBGRAD || MODE == LD_PLAIN) return r0;   // LD_PLAIN: a raw channel-major operand (K, Ppad)
     f32x16 out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -962,6 +962,244 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
                                n.arg, n.dg, 256, B);
             P2N_CHECK_HIP(hipGetLastError());
         }
+    }
+    return P2N_OK;
+}
+
+// =========================================================================== generic shared MLP, train mode
+// [Conv1d(k=1) -> BatchNorm1d(batch statistics) -> ReLU] x nl (the last layer optionally a plain Conv1d) over a
+// channel-major matrix x (dims[0], Ppad) whose P real columns are every (cloud, point[, neighbour]) of the batch:
+// the shared MLP of a set-abstraction / feature-propagation level in train() mode, with the same kernels as the
+// Point2Net training path above (layer GEMM with the BatchNorm/ReLU forward or backward in its operand loader,
+// pivot-shifted row statistics, weight gradient over points).  No counterpart in the reference (it has no
+// hierarchical levels); semantics are torch's nn.Sequential(Conv1d, BatchNorm1d, ReLU, ...) in train() mode.
+#define MLP_MAX_LAYERS 8
+
+// out[c][p] = relu(z[c][p]*s[c] + t[c]): the chain's last activation, materialised once for the caller
+__global__ __launch_bounds__(256) void p2n_bnrelu_apply_kernel(const float *__restrict__ z, const float *__restrict__ tab,
+                                                               int rows, long Ppad, float *__restrict__ out) {
+    const int c = blockIdx.y;
+    const float s = tab[c], t = tab[rows + c];
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= Ppad) return;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(z + (long)c * Ppad + p);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(v[j], s, t), 0.f);
+    *reinterpret_cast<f32x4 *>(out + (long)c * Ppad + p) = o;
+}
+
+namespace {
+struct Mlp {
+    int nl, dims[MLP_MAX_LAYERS + 1], last_plain;
+    long P, Ppad;
+    const float *W[MLP_MAX_LAYERS], *b[MLP_MAX_LAYERS], *gamma[MLP_MAX_LAYERS], *beta[MLP_MAX_LAYERS];
+    float *rmean[MLP_MAX_LAYERS], *rvar[MLP_MAX_LAYERS];
+    float *z[MLP_MAX_LAYERS], *ftab[MLP_MAX_LAYERS], *btab, *part, *wimg, *da[2];
+    int *mode;
+};
+
+int mlp_init(Mlp &m, const char *fn, long P, int nl, const int *dims, int last_plain) {
+    P2N_REQUIRE(nl >= 1 && nl <= MLP_MAX_LAYERS && dims, "%s: 1..%d layers", fn, MLP_MAX_LAYERS);
+    P2N_REQUIRE(P >= 2 && P < (1L << 31) - 256, "%s: %ld columns (train-mode BatchNorm needs at least 2; at most 2^31)", fn, P);
+    P2N_REQUIRE(dims[0] >= 1 && dims[0] <= 1024, "%s: %d input channels not in [1,1024]", fn, dims[0]);
+    for (int l = 1; l <= nl; ++l)
+        P2N_REQUIRE(dims[l] >= 1 && dims[l] <= 256, "%s: layer %d has %d output channels, not in [1,256]", fn, l - 1, dims[l]);
+    m.nl = nl; m.last_plain = last_plain ? 1 : 0; m.P = P; m.Ppad = (P + 127) / 128 * 128;
+    for (int l = 0; l <= nl; ++l) m.dims[l] = dims[l];
+    return P2N_OK;
+}
+
+size_t mlp_carve(Mlp &m, char *base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    int hid = 1, kmax = m.dims[0];
+    for (int l = 0; l < m.nl; ++l) {
+        const bool plain = m.last_plain && l == m.nl - 1;
+        m.z[l] = plain ? nullptr : (float *)take(sizeof(float) * (size_t)m.dims[l + 1] * m.Ppad);
+        m.ftab[l] = (float *)take(sizeof(float) * 4 * m.dims[l + 1]);
+        if (l + 1 < m.nl && m.dims[l + 1] > hid) hid = m.dims[l + 1];
+        if (m.dims[l + 1] > kmax) kmax = m.dims[l + 1];
+    }
+    m.btab = (float *)take(sizeof(float) * 5 * 256);
+    m.part = (float *)take(sizeof(float) * 2 * 256 * STAT_S);
+    // weight image: 8 row tiles x ceil(kmax/32) k-tiles x 1024 floats, + the spare chunks the prefetch may touch
+    m.wimg = (float *)take(sizeof(float) * ((size_t)8 * ((kmax + 31) / 32) * 1024 + 2 * 32 * 256));
+    m.da[0] = (float *)take(sizeof(float) * (size_t)hid * m.Ppad);
+    m.da[1] = (float *)take(sizeof(float) * (size_t)hid * m.Ppad);
+    m.mode = (int *)take(sizeof(int));
+    return off;
+}
+
+void mlp_bind(Mlp &m, const void *const *ptrs) {
+    int i = 0;
+    for (int l = 0; l < m.nl; ++l) {
+        m.W[l] = (const float *)ptrs[i++]; m.b[l] = (const float *)ptrs[i++];
+        m.gamma[l] = (const float *)ptrs[i++]; m.beta[l] = (const float *)ptrs[i++];
+        m.rmean[l] = (float *)ptrs[i++]; m.rvar[l] = (float *)ptrs[i++];
+    }
+}
+}  // namespace
+
+extern "C" size_t p2n_mlp_train_workspace_bytes(long P, int nl, const int *dims, int last_plain) {
+    Mlp m;
+    if (mlp_init(m, "p2n_mlp_train_workspace_bytes", P, nl, dims, last_plain)) return 0;
+    return mlp_carve(m, nullptr);
+}
+
+// x_cm (dims[0], Ppad) -> out_cm (dims[nl], Ppad), Ppad = P rounded up to 128 (pad columns of x_cm must be finite;
+// they never reach a statistic or a gradient).  params_host: HOST array of 6 DEVICE pointers per layer
+// (W (cout,cin), b, gamma, beta, running_mean, running_var; the last four NULL for a plain last layer);
+// running statistics are updated in place with `momentum` (unbiased variance, as torch).  eps is 1e-5.
+// The workspace keeps what p2n_mlp_train_backward needs and must stay untouched until then.
+extern "C" int p2n_mlp_train_forward(const float *x_cm, long P, int nl, const int *dims, int last_plain,
+                                     const void *const *params_host, float momentum, float *out_cm, void *workspace,
+                                     size_t workspace_bytes, void *stream_) {
+    Mlp m;
+    TRY(mlp_init(m, "p2n_mlp_train_forward", P, nl, dims, last_plain));
+    P2N_REQUIRE(x_cm && params_host && out_cm, "p2n_mlp_train_forward: null pointer");
+    P2N_REQUIRE(momentum >= 0.f && momentum <= 1.f, "p2n_mlp_train_forward: momentum %g not in [0,1]", momentum);
+    const size_t need = mlp_carve(m, nullptr);
+    if (!workspace || workspace_bytes < need) {
+        p2n_set_error("p2n_mlp_train_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    P2N_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)x_cm & 15) == 0 && ((uintptr_t)out_cm & 15) == 0,
+                "p2n_mlp_train_forward: workspace must be 256-byte, x_cm / out_cm 16-byte aligned");
+    mlp_carve(m, (char *)workspace);
+    mlp_bind(m, params_host);
+    for (int l = 0; l < nl; ++l) {
+        const bool plain = m.last_plain && l == nl - 1;
+        P2N_REQUIRE(m.W[l] && m.b[l] && (plain || (m.gamma[l] && m.beta[l] && m.rmean[l] && m.rvar[l])),
+                    "p2n_mlp_train_forward: null parameter pointer in layer %d", l);
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    P2N_CHECK_HIP(hipMemsetAsync(m.mode, 0, sizeof(int), s));
+    const int P32 = (int)P, Pp = (int)m.Ppad;
+    for (int l = 0; l < nl; ++l) {
+        const bool plain = m.last_plain && l == nl - 1;
+        const int K = m.dims[l], rows = m.dims[l + 1];
+        TRY(pack_w(m.W[l], K, 0, rows, K, 0, m.wimg, s));
+        LayerArgs a = {};
+        a.wimg = m.wimg; a.bias = m.b[l]; a.K = K; a.rows = rows; a.P = P32; a.Ppad = Pp; a.N = P32;
+        a.out = plain ? out_cm : m.z[l];
+        if (l == 0) { a.in0 = x_cm; TRY((launch_layer<LD_PLAIN, false>(a, s))); }
+        else { a.in0 = m.z[l - 1]; a.tab = m.ftab[l - 1]; TRY((launch_layer<LD_BNRELU, false>(a, s))); }
+        if (plain) break;
+        StatArgs st = {};
+        st.z = m.z[l]; st.part = m.part; st.rows = rows; st.P = P32; st.Ppad = Pp; st.S = STAT_S; st.N = P32;
+        hipLaunchKernelGGL(p2n_row_stats_kernel<ST_FWD>, dim3(rows, STAT_S), dim3(256), 0, s, st);
+        P2N_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(p2n_bn_finalize_fwd_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, m.part, m.z[l], Pp, rows, STAT_S,
+                           P32, m.gamma[l], m.beta[l], m.rmean[l], m.rvar[l], momentum, m.ftab[l]);
+        P2N_CHECK_HIP(hipGetLastError());
+        if (l == nl - 1) {
+            hipLaunchKernelGGL(p2n_bnrelu_apply_kernel, dim3((unsigned)((m.Ppad / 4 + 255) / 256), rows), dim3(256), 0, s,
+                               m.z[l], m.ftab[l], rows, m.Ppad, out_cm);
+            P2N_CHECK_HIP(hipGetLastError());
+        }
+    }
+    return P2N_OK;
+}
+
+// Backward of p2n_mlp_train_forward (same workspace).  dout_cm (dims[nl], Ppad) is d loss / d out_cm and is
+// OVERWRITTEN (it ends up holding dz of the last layer).  grads_host: HOST array of 4 DEVICE pointers per layer
+// (dW, db, dgamma, dbeta; the last two NULL for a plain last layer), each fully overwritten.  dx_cm
+// (dims[0], Ppad) receives d loss / d x_cm, or NULL when the input needs no gradient (then the first layer's
+// weight gradient forms dz in its own loader and no data gradient is computed for it).
+extern "C" int p2n_mlp_train_backward(const float *x_cm, float *dout_cm, long P, int nl, const int *dims, int last_plain,
+                                      const void *const *params_host, void *const *grads_host, float *dx_cm,
+                                      void *workspace, size_t workspace_bytes, void *stream_) {
+    Mlp m;
+    TRY(mlp_init(m, "p2n_mlp_train_backward", P, nl, dims, last_plain));
+    P2N_REQUIRE(x_cm && dout_cm && params_host && grads_host, "p2n_mlp_train_backward: null pointer");
+    const size_t need = mlp_carve(m, nullptr);
+    if (!workspace || workspace_bytes < need) {
+        p2n_set_error("p2n_mlp_train_backward: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    P2N_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)x_cm & 15) == 0 && ((uintptr_t)dout_cm & 15) == 0 &&
+                ((uintptr_t)dx_cm & 15) == 0, "p2n_mlp_train_backward: workspace must be 256-byte, matrices 16-byte aligned");
+    mlp_carve(m, (char *)workspace);
+    mlp_bind(m, params_host);
+    float *dW[MLP_MAX_LAYERS], *db[MLP_MAX_LAYERS], *dgam[MLP_MAX_LAYERS], *dbet[MLP_MAX_LAYERS];
+    for (int l = 0; l < nl; ++l) {
+        dW[l] = (float *)grads_host[4 * l]; db[l] = (float *)grads_host[4 * l + 1];
+        dgam[l] = (float *)grads_host[4 * l + 2]; dbet[l] = (float *)grads_host[4 * l + 3];
+        const bool plain = m.last_plain && l == nl - 1;
+        P2N_REQUIRE(dW[l] && db[l] && (plain || (dgam[l] && dbet[l])), "p2n_mlp_train_backward: null gradient pointer in layer %d", l);
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    const int P32 = (int)P, Pp = (int)m.Ppad;
+    for (int l = 0; l < nl; ++l)
+        P2N_CHECK_HIP(hipMemsetAsync(dW[l], 0, sizeof(float) * (size_t)m.dims[l] * m.dims[l + 1], s));
+
+    // da_{l-1} = W_l^T . dz_l for the layer whose dz (or da, with `bnbwd`) sits in `src`; at most 256 output rows per
+    // launch.  The first launch of a BatchNorm layer leaves dz in place of da; any further row block reads that dz.
+    auto dgrad = [&](int l, float *src, float *dst, bool bnbwd) -> int {
+        const int C = m.dims[l + 1], rows_all = m.dims[l];
+        for (int r0 = 0; r0 < rows_all; r0 += 256) {
+            const int rows = rows_all - r0 < 256 ? rows_all - r0 : 256;
+            TRY(pack_w(m.W[l], rows_all, r0, rows, C, 1, m.wimg, s));
+            LayerArgs a = {};
+            a.in0 = src; a.wimg = m.wimg; a.K = C; a.rows = rows; a.P = P32; a.Ppad = Pp; a.N = P32;
+            a.out = dst + (size_t)r0 * m.Ppad;
+            if (bnbwd && r0 == 0) {
+                a.in1 = m.z[l]; a.tab = m.btab; a.dz_out = src;
+                TRY((launch_layer<LD_BNBWD, false>(a, s)));
+            } else {
+                TRY((launch_layer<LD_PLAIN, false>(a, s)));
+            }
+        }
+        return P2N_OK;
+    };
+    // dW_l = dz_l . a_{l-1}^T with dz_l in `dz` (plain), a_{l-1} = relu(bn(z_{l-1})) or the raw input
+    auto wgrad = [&](int l, const float *dz) -> int {
+        WgArgs w = {};
+        w.a0 = dz; w.dW = dW[l]; w.rows = m.dims[l + 1]; w.cols = m.dims[l]; w.ldw = m.dims[l]; w.P = P32; w.Ppad = Pp;
+        if (l == 0) { w.b0 = x_cm; return launch_wgrad<LD_PLAIN, LD_PLAIN>(w, s); }
+        w.b0 = m.z[l - 1]; w.btab = m.ftab[l - 1];
+        return launch_wgrad<LD_PLAIN, LD_BNRELU>(w, s);
+    };
+    auto target = [&](int l, int cur) -> float * { return l == 0 ? dx_cm : m.da[cur]; };   // where da_{l-1} goes
+
+    float *src = dout_cm;
+    int cur = 0;
+    int l = nl - 1;
+    if (m.last_plain) {   // dz = dout: bias gradient = row sums, then the two GEMMs
+        StatArgs sc = {};
+        sc.z = dout_cm; sc.da = dout_cm; sc.part = db[l]; sc.rows = m.dims[l + 1]; sc.P = P32; sc.Ppad = Pp; sc.S = 1; sc.N = P32;
+        hipLaunchKernelGGL(p2n_row_stats_kernel<ST_PLAINCLOUD>, dim3(m.dims[l + 1], 1), dim3(256), 0, s, sc);
+        P2N_CHECK_HIP(hipGetLastError());
+        TRY(wgrad(l, src));
+        if (l > 0 || dx_cm) {
+            float *dst = target(l, cur);
+            TRY(dgrad(l, src, dst, false));
+            src = dst; cur ^= 1;
+        }
+        --l;
+    }
+    for (; l >= 0; --l) {
+        const int C = m.dims[l + 1];
+        StatArgs st = {};
+        st.z = m.z[l]; st.da = src; st.tab = m.ftab[l]; st.part = m.part;
+        st.rows = C; st.P = P32; st.Ppad = Pp; st.S = STAT_S; st.N = P32;
+        hipLaunchKernelGGL(p2n_row_stats_kernel<ST_BWD>, dim3(C, STAT_S), dim3(256), 0, s, st);
+        P2N_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(p2n_bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, s, m.part, C, STAT_S, P32, m.gamma[l],
+                           m.ftab[l], dgam[l], dbet[l], m.btab, m.mode, db[l]);
+        P2N_CHECK_HIP(hipGetLastError());
+        if (l == 0 && !dx_cm) {   // nothing below: the weight gradient forms dz in its own loader
+            WgArgs w = {};
+            w.a0 = src; w.a1 = m.z[0]; w.atab = m.btab; w.dW = dW[0];
+            w.rows = C; w.cols = m.dims[0]; w.ldw = m.dims[0]; w.P = P32; w.Ppad = Pp; w.b0 = x_cm;
+            TRY((launch_wgrad<LD_BNBWD, LD_PLAIN>(w, s)));
+            break;
+        }
+        float *dst = target(l, cur);
+        TRY(dgrad(l, src, dst, true));   // leaves dz_l in src
+        TRY(wgrad(l, src));
+        src = dst; cur ^= 1;
     }
     return P2N_OK;
 }

@@ -11,7 +11,10 @@ GPU tensors in eval mode run libp2n_hip.so end to end (p2n_fps, p2n_ball_query,
 p2n_sa_group, p2n_pointwise_layer, p2n_group_max, p2n_three_nn, p2n_three_interpolate).
 CPU tensors run a stock-PyTorch composition of the same formulas (same index rules: exact
 fp32 squared distances, lowest index first), which is what the tests compare against
-(parity unpinned by the reference).  Training this variant on the GPU is not implemented.
+(parity unpinned by the reference).  In train() mode GPU tensors take the per-operator composition with
+train-mode shared MLPs (p2n_mlp_train_forward / p2n_mlp_train_backward: batch-statistics BatchNorm, weight and data
+gradients as fp32 MFMA GEMMs) and the operators' adjoints (p2n_group_gather_bwd, p2n_three_interpolate_bwd); the max
+over a group and the concatenations go through autograd.
 """
 import ctypes
 from typing import List, Optional
@@ -30,7 +33,10 @@ def _sqdist(a, b):
     return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
 
 
+# Indices and interpolation weights are always computed from the float32 coordinates, also when a float64 copy of
+# the module runs as a low-noise reference for the gradients: the index rules are defined on fp32 distances.
 def fps_torch(xyz, npoint, start_idx=0):
+    xyz = xyz.float()
     B, N, _ = xyz.shape
     idx = torch.zeros(B, npoint, dtype=torch.long)
     mind = torch.full((B, N), float("inf"))
@@ -48,7 +54,7 @@ def fps_torch(xyz, npoint, start_idx=0):
 
 def ball_query_torch(xyz, new_xyz, radius, nsample):
     B, N, _ = xyz.shape
-    d2 = _sqdist(new_xyz, xyz)
+    d2 = _sqdist(new_xyz.float(), xyz.float())
     r2 = torch.tensor(radius, dtype=torch.float32) * torch.tensor(radius, dtype=torch.float32)
     cand = torch.where(d2 < r2, torch.arange(N).view(1, 1, N), torch.tensor(N))
     cand = cand.sort(dim=2).values[:, :, :nsample]
@@ -58,7 +64,7 @@ def ball_query_torch(xyz, new_xyz, radius, nsample):
 
 
 def three_nn_torch(unknown, known):
-    d2 = _sqdist(unknown, known)
+    d2 = _sqdist(unknown.float(), known.float())
     order = torch.argsort(d2, dim=2, stable=True)[:, :, :3]
     d = torch.gather(d2, 2, order)
     r = 1.0 / (d + 1e-8)
@@ -144,8 +150,104 @@ def gather_xyz(rows: torch.Tensor, ld: int, idx: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ shared MLP
+def _to_cm(x: torch.Tensor, Ppad: int) -> torch.Tensor:
+    """(B,C,L) -> channel-major (C, Ppad) over the flattened batch, pad columns zero"""
+    B, C, L = x.shape
+    out = torch.zeros((C, Ppad), dtype=torch.float32, device=x.device) if Ppad != B * L else \
+        torch.empty((C, Ppad), dtype=torch.float32, device=x.device)
+    out[:, :B * L].view(C, B, L).copy_(x.permute(1, 0, 2))
+    return out
+
+
+def _from_cm(m: torch.Tensor, B: int, L: int) -> torch.Tensor:
+    """channel-major (C, Ppad) -> (B,C,L) contiguous"""
+    C = m.shape[0]
+    return m[:, :B * L].view(C, B, L).permute(1, 0, 2).contiguous()
+
+
+class _SharedMLPTrainFn(torch.autograd.Function):
+    """Train-mode shared MLP on GPU tensors: p2n_mlp_train_forward / p2n_mlp_train_backward (batch-statistics
+    BatchNorm with the running buffers updated in place, as nn.BatchNorm1d in train() mode)."""
+
+    @staticmethod
+    def forward(ctx, x, dims, last_plain, momentum, buffers, *params):
+        L_ = _lib.lib()
+        x = _rt.require_cuda_f32(x, "x")
+        B, C, L = x.shape
+        P = B * L
+        Ppad = (P + 127) // 128 * 128
+        nl = len(dims) - 1
+        dev = x.device
+        arr = (ctypes.c_int * len(dims))(*dims)
+        nbytes = L_.p2n_mlp_train_workspace_bytes(P, nl, arr, int(last_plain))
+        if nbytes == 0:
+            raise ValueError("p2n_mlp_train_workspace_bytes: " + L_.p2n_last_error().decode(errors="replace"))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # holds the activations until the backward
+        x_cm = _to_cm(x, Ppad)
+        out_cm = torch.empty((dims[-1], Ppad), dtype=torch.float32, device=dev)
+        table, pi = [], 0
+        for l in range(nl):
+            plain = last_plain and l == nl - 1
+            w, b = params[pi], params[pi + 1]
+            pi += 2
+            if plain:
+                table += [w, b, None, None, None, None]
+            else:
+                g, be = params[pi], params[pi + 1]
+                pi += 2
+                table += [w, b, g, be, buffers[2 * l], buffers[2 * l + 1]]
+        for t in table:
+            if t is not None and not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("shared-MLP parameters and buffers must be contiguous float32 tensors on the input's GPU")
+        ptrs = (ctypes.c_void_p * len(table))(*[None if t is None else t.data_ptr() for t in table])
+        with torch.cuda.device(dev):
+            _lib.check(L_.p2n_mlp_train_forward(x_cm.data_ptr(), P, nl, arr, int(last_plain), ptrs, float(momentum),
+                                                out_cm.data_ptr(), ws.data_ptr(), ws.numel(), _rt.stream_handle(dev)),
+                       "p2n_mlp_train_forward")
+        ctx.save_for_backward(x_cm, ws, *params)
+        ctx.meta = (dims, bool(last_plain), B, L, P, Ppad, table)
+        ctx.done = False
+        return _from_cm(out_cm, B, L)
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.done:
+            raise RuntimeError("the shared MLP's saved activations were consumed by a previous backward "
+                               "(retain_graph is not supported on this path)")
+        ctx.done = True
+        L_ = _lib.lib()
+        dims, last_plain, B, L, P, Ppad, table = ctx.meta
+        x_cm, ws = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        params = ctx.saved_tensors[2:]
+        nl = len(dims) - 1
+        dev = x_cm.device
+        arr = (ctypes.c_int * len(dims))(*dims)
+        dout_cm = _to_cm(_rt.require_cuda_f32(gout, "grad_output"), Ppad)      # a private copy: the call overwrites it
+        grads = [torch.empty_like(p) for p in params]
+        gtab, gi = [], 0
+        for l in range(nl):
+            plain = last_plain and l == nl - 1
+            if plain:
+                gtab += [grads[gi], grads[gi + 1], None, None]
+                gi += 2
+            else:
+                gtab += grads[gi:gi + 4]
+                gi += 4
+        need_dx = ctx.needs_input_grad[0]
+        dx_cm = torch.empty((dims[0], Ppad), dtype=torch.float32, device=dev) if need_dx else None
+        ptrs = (ctypes.c_void_p * len(table))(*[None if t is None else t.data_ptr() for t in table])
+        gptrs = (ctypes.c_void_p * len(gtab))(*[None if t is None else t.data_ptr() for t in gtab])
+        with torch.cuda.device(dev):
+            _lib.check(L_.p2n_mlp_train_backward(x_cm.data_ptr(), dout_cm.data_ptr(), P, nl, arr, int(last_plain), ptrs,
+                                                 gptrs, _rt.ptr(dx_cm), ws.data_ptr(), ws.numel(), _rt.stream_handle(dev)),
+                       "p2n_mlp_train_backward")
+        dx = _from_cm(dx_cm, B, L) if need_dx else None
+        return (dx, None, None, None, None, *grads)
+
+
 class SharedMLP(nn.Module):
-    """[Conv1d(k=1) + BatchNorm1d + ReLU] x n over (B,C,L); eval on GPU = p2n_pointwise_layer."""
+    """[Conv1d(k=1) + BatchNorm1d + ReLU] x n over (B,C,L).  GPU tensors: eval = p2n_pointwise_layer (or the
+    fused level kernels), train / autograd = p2n_mlp_train_forward + p2n_mlp_train_backward."""
 
     def __init__(self, channels: List[int], last_plain: bool = False):
         super().__init__()
@@ -174,11 +276,45 @@ class SharedMLP(nn.Module):
                 i += 1
         return out
 
+    def _forward_train(self, x):
+        mods, i = list(self.net), 0
+        dims, params, buffers, bns, last_plain = [mods[0].in_channels], [], [], [], False
+        while i < len(mods):
+            conv = mods[i]
+            dims.append(conv.out_channels)
+            params += [conv.weight, conv.bias]
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                bn = mods[i + 1]
+                if bn.momentum is None:
+                    raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not implemented on the GPU path")
+                if abs(bn.eps - 1e-5) > 1e-12 or not bn.affine or not bn.track_running_stats:
+                    raise NotImplementedError("the GPU shared MLP needs BatchNorm1d(eps=1e-5, affine=True, track_running_stats=True)")
+                params += [bn.weight, bn.bias]
+                buffers += [bn.running_mean, bn.running_var]
+                bns.append(bn)
+                i += 3
+            else:
+                if i + 1 != len(mods):
+                    raise NotImplementedError("only the last layer of a shared MLP may be a plain Conv1d")
+                last_plain = True
+                buffers += [None, None]
+                i += 1
+        if len({bn.momentum for bn in bns}) > 1:
+            raise NotImplementedError("the BatchNorm layers of one shared MLP must share one momentum")
+        momentum = bns[0].momentum if bns else 0.1
+        y = _SharedMLPTrainFn.apply(x, tuple(dims), last_plain, momentum, tuple(buffers), *params)
+        for bn in bns:
+            bn.num_batches_tracked += 1
+        return y
+
     def forward(self, x):                                   # (B,C,L)
         if not x.is_cuda:
             return self.net(x)
-        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("Point2NetSA trains on CPU tensors only; on the GPU use eval() + no_grad()")
+        if self.training:
+            return self._forward_train(x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("differentiating through eval-mode BatchNorm is not implemented for the hierarchical "
+                                      "levels on the GPU: call train(), or eval() under torch.no_grad()")
         L = _lib.lib()
         x = _rt.require_cuda_f32(x, "x")
         B, _, n = x.shape
@@ -245,6 +381,16 @@ class SetAbstraction(nn.Module):
             new_xyz = ops.group_gather(xyz_t, fidx.unsqueeze(2)).squeeze(3).transpose(1, 2).contiguous()
             gidx = ops.ball_query(xyz, new_xyz, self.radius, ns)
             C = 0 if feat is None else feat.size(1)
+            if self.training and torch.is_grad_enabled():
+                # differentiable composition: relative coordinates (no gradient) ++ gathered features (p2n_group_gather
+                # with its scatter-add adjoint), train-mode shared MLP, max over the group through autograd
+                rel = torch.empty((B, 3, M, ns), dtype=torch.float32, device=xyz.device)
+                with torch.cuda.device(xyz.device):
+                    _lib.check(L.p2n_sa_group(xyz.data_ptr(), new_xyz.data_ptr(), None, gidx.data_ptr(), B, 0, N, M, ns,
+                                              rel.data_ptr(), _rt.stream_handle(xyz.device)), "p2n_sa_group")
+                grouped = rel if feat is None else torch.cat([rel, ops.group_gather(feat.contiguous(), gidx)], dim=1)
+                y = self.mlp(grouped.view(B, C + 3, M * ns)).view(B, -1, M, ns)
+                return new_xyz, y.max(dim=3).values
             grouped = torch.empty((B, C + 3, M, ns), dtype=torch.float32, device=xyz.device)
             with torch.cuda.device(xyz.device):
                 _lib.check(L.p2n_sa_group(xyz.data_ptr(), new_xyz.data_ptr(), _rt.ptr(feat), gidx.data_ptr(), B, C, N, M,
@@ -353,7 +499,7 @@ class Point2NetSA(nn.Module):
     # ---- GPU eval: one fused kernel per level, features point-major between levels -------------------
     def _fused_ok(self) -> bool:
         if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            return False      # the per-operator path raises its NotImplementedError for GPU training
+            return False      # training / autograd: the per-operator path (train-mode shared MLPs, differentiable operators)
         c = self.feature_dim - 3
         return (self.sa1.fused_supported() and self.sa2.fused_supported() and self.sa3.fused_supported()
                 and self.fp3.fused_supported(self.sa2.mlp.net[-3].out_channels)
