@@ -245,6 +245,48 @@ class _SharedMLPTrainFn(torch.autograd.Function):
         return (dx, None, None, None, None, *grads)
 
 
+def shared_mlp_train(net: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Train-mode forward, with autograd, of nn.Sequential(Conv1d(k=1), BatchNorm1d, ReLU, ... [, Conv1d(k=1)]) on a
+    GPU tensor (B,C,L) through p2n_mlp_train_forward / p2n_mlp_train_backward; BatchNorm buffers are updated as
+    nn.BatchNorm1d does in train() mode."""
+    mods, i = list(net), 0
+    if not mods or not isinstance(mods[0], nn.Conv1d):
+        raise NotImplementedError("a shared MLP starts with a Conv1d")
+    dims, params, buffers, bns, last_plain = [mods[0].in_channels], [], [], [], False
+    while i < len(mods):
+        conv = mods[i]
+        if not isinstance(conv, nn.Conv1d) or conv.kernel_size != (1,) or conv.bias is None:
+            raise NotImplementedError("the GPU shared MLP is built from Conv1d(kernel_size=1, bias=True) layers")
+        dims.append(conv.out_channels)
+        params += [conv.weight, conv.bias]
+        if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+            bn = mods[i + 1]
+            if not (i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)):
+                raise NotImplementedError("every BatchNorm1d of a GPU shared MLP is followed by a ReLU")
+            if bn.momentum is None:
+                raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not implemented on the GPU path")
+            if abs(bn.eps - 1e-5) > 1e-12 or not bn.affine or not bn.track_running_stats:
+                raise NotImplementedError("the GPU shared MLP needs BatchNorm1d(eps=1e-5, affine=True, track_running_stats=True)")
+            params += [bn.weight, bn.bias]
+            buffers += [bn.running_mean, bn.running_var]
+            bns.append(bn)
+            i += 3
+        else:
+            if i + 1 != len(mods):
+                raise NotImplementedError("only the last layer of a shared MLP may be a plain Conv1d")
+            last_plain = True
+            buffers += [None, None]
+            i += 1
+    if len({bn.momentum for bn in bns}) > 1:
+        raise NotImplementedError("the BatchNorm layers of one shared MLP must share one momentum")
+    momentum = bns[0].momentum if bns else 0.1
+    y = _SharedMLPTrainFn.apply(x, tuple(dims), last_plain, momentum, tuple(buffers), *params)
+    with torch.no_grad():
+        for bn in bns:
+            bn.num_batches_tracked += 1
+    return y
+
+
 class SharedMLP(nn.Module):
     """[Conv1d(k=1) + BatchNorm1d + ReLU] x n over (B,C,L).  GPU tensors: eval = p2n_pointwise_layer (or the
     fused level kernels), train / autograd = p2n_mlp_train_forward + p2n_mlp_train_backward."""
@@ -277,35 +319,7 @@ class SharedMLP(nn.Module):
         return out
 
     def _forward_train(self, x):
-        mods, i = list(self.net), 0
-        dims, params, buffers, bns, last_plain = [mods[0].in_channels], [], [], [], False
-        while i < len(mods):
-            conv = mods[i]
-            dims.append(conv.out_channels)
-            params += [conv.weight, conv.bias]
-            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
-                bn = mods[i + 1]
-                if bn.momentum is None:
-                    raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not implemented on the GPU path")
-                if abs(bn.eps - 1e-5) > 1e-12 or not bn.affine or not bn.track_running_stats:
-                    raise NotImplementedError("the GPU shared MLP needs BatchNorm1d(eps=1e-5, affine=True, track_running_stats=True)")
-                params += [bn.weight, bn.bias]
-                buffers += [bn.running_mean, bn.running_var]
-                bns.append(bn)
-                i += 3
-            else:
-                if i + 1 != len(mods):
-                    raise NotImplementedError("only the last layer of a shared MLP may be a plain Conv1d")
-                last_plain = True
-                buffers += [None, None]
-                i += 1
-        if len({bn.momentum for bn in bns}) > 1:
-            raise NotImplementedError("the BatchNorm layers of one shared MLP must share one momentum")
-        momentum = bns[0].momentum if bns else 0.1
-        y = _SharedMLPTrainFn.apply(x, tuple(dims), last_plain, momentum, tuple(buffers), *params)
-        for bn in bns:
-            bn.num_batches_tracked += 1
-        return y
+        return shared_mlp_train(self.net, x)
 
     def forward(self, x):                                   # (B,C,L)
         if not x.is_cuda:
