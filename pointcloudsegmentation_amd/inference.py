@@ -36,8 +36,8 @@ def predict(model, points, colors=None, eps: float = 0.1, min_samples: int = 50,
 @torch.no_grad()
 def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap: bool = True):
     """predict() over a sequence of scenes [(points, colors | None), ...] as a three-stage pipeline on one
-    GPU: while scene i runs normalise -> forward -> cluster on the compute stream, scene i+1's arrays are
-    already being uploaded from pinned staging buffers on a second stream, and scene i-1's labels and
+    GPU: while scene i runs forward -> cluster on the compute stream, scene i+1's arrays are already being
+    uploaded from pinned staging buffers and normalised on a second stream, and scene i-1's labels and
     embeddings leave through pinned buffers on a third (reference inference.py:168-176 does upload, forward,
     download and clustering one after the other on one stream).  Yields the same dict per scene as predict().
     overlap=False runs the scenes one by one through predict() (the comparison tools/bench_inference.py
@@ -72,10 +72,15 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
         with torch.cuda.stream(up):
             p = p_h[:n].to(dev, non_blocking=True)
             c = c_h[:n].to(dev, non_blocking=True) if col is not None else None
+            copied = torch.cuda.Event()
+            copied.record(up)
+            # the normalisation rides on the upload stream too: its float64 row sum is one dependent chain on one
+            # CU (numpy's order), which hides completely beside the previous scene's forward and clustering
+            feat, cs = preprocess_point_cloud(p, c, sync=False)
             ev = torch.cuda.Event()
             ev.record(up)
-        last[0] = ev
-        return p, c, ev
+        last[0] = copied
+        return feat, cs, ev
 
     # Results leave through a ring of three pinned slots sized for the largest scene and are copied out into
     # ordinary arrays when yielded: a fresh pinned allocation per scene would wait for the busy GPU
@@ -96,14 +101,12 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
     pending = None
     nxt = stage(0) if scenes else None
     for i in range(len(scenes)):
-        p, c, ev = nxt
+        feat, cs, ev = nxt
         main.wait_event(ev)
-        for t in (p, c):
-            if t is not None:
-                t.record_stream(main)
+        for t in (feat, cs):
+            t.record_stream(main)
         if i + 1 < len(scenes):
-            nxt = stage(i + 1)                               # upload of scene i+1 beside the compute of scene i
-        feat, cs = preprocess_point_cloud(p, c, sync=False)
+            nxt = stage(i + 1)                               # upload + normalisation of scene i+1 beside the compute of scene i
         emb = model(feat)[0]
         labels = cluster_embeddings(emb, eps=eps, min_samples=min_samples)
         num = _count_labels(labels)
