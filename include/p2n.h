@@ -151,6 +151,20 @@ int p2n_instance_seg_loss(const float *points, const float *emb, const int32_t *
                           float *demb_pull, float *demb_push, float *demb_smooth,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* Label densification for p2n_instance_seg_loss (reference losses.py:389-395: torch.unique per cloud): labels (B,N)
+ * int64 -> inst (B*N) dense ids ascending in (cloud,label); cnt / bg (capacity B*max_per_cloud each, the first
+ * cstart[B] entries written); cstart (B+1); overflow (1 int): set when a cloud holds more than max_per_cloud distinct
+ * labels (or the value INT64_MAX) -- the outputs are then unusable and the caller takes another route.  Everything
+ * stays on the device; the caller reads cstart[B] (= T) and overflow. */
+size_t p2n_dense_instances_workspace_bytes(int B, int max_per_cloud);
+int p2n_dense_instances(const long long *labels, int B, int N, int max_per_cloud, int32_t *inst, int32_t *cnt,
+                        int32_t *bg, int32_t *cstart, int32_t *overflow,
+                        void *workspace, size_t workspace_bytes, void *stream);
+/* out = (g3[0]*a + g3[1]*b) + g3[2]*c over n floats (n % 4 == 0, 16-byte aligned), g3 on the device: the loss's
+ * backward (reference losses.py:365 under autograd: upstream gradients of pull / push / smoothness times the three
+ * embedding gradients p2n_instance_seg_loss stored), one pass. */
+int p2n_combine3(const float *g3, const float *a, const float *b, const float *c, long n, float *out, void *stream);
+
 /* ---- point-set operators (named by BASELINE.json north_star; the reference has
  * none of them -- SURVEY.md section 0 -- so oracle/p2n_oracle.c is their spec:
  * fp32 squared distance ((dx*dx+dy*dy)+dz*dz) without fma, lowest index wins

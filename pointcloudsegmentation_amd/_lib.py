@@ -58,6 +58,9 @@ SIGNATURES = {
     "p2n_mlp_train_workspace_bytes": (c_sz, [ctypes.c_long, c_int, c_vp, c_int]),
     "p2n_mlp_train_forward": (c_int, [c_f, ctypes.c_long, c_int, c_vp, c_int, c_vp, c_float, c_f, c_vp, c_sz, c_vp]),
     "p2n_mlp_train_backward": (c_int, [c_f, c_f, ctypes.c_long, c_int, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_sz, c_vp]),
+    "p2n_dense_instances_workspace_bytes": (c_sz, [c_int, c_int]),
+    "p2n_dense_instances": (c_int, [c_vp, c_int, c_int, c_int, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "p2n_combine3": (c_int, [c_f, c_f, c_f, c_f, ctypes.c_long, c_f, c_vp]),
     "p2n_instance_seg_loss_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "p2n_instance_seg_loss": (c_int, [c_f, c_f, c_i, c_i, c_i, c_i, c_int, c_int, c_int, c_int, c_float, c_float,
                                       c_int, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),

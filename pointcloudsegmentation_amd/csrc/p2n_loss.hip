@@ -957,3 +957,193 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
+
+// =========================================================================== label densification
+// The loss kernels want every point's (cloud, label) pair as a dense id, ids ascending in (cloud, label) -- what
+// reference losses.py:389-395 gets from torch.unique per cloud.  Through torch.unique on the device that is a radix
+// sort + merge passes + scans: ~55 launches, 0.56 ms per step at 32 x 8192, all launch latency.  A cloud has tens of
+// instances, so here one workgroup per cloud keeps its labels in registers and peels off the distinct values in
+// ascending order: pass i counts the points equal to the i-th smallest label and finds the next larger one (one
+// 64-bit min + one add reduction per pass).  Clouds with more than `max_per_cloud` distinct labels set the overflow
+// flag and the caller takes another route.
+#define DI_THREADS 1024
+#define DI_PER_THREAD 16   // labels held in registers: N <= 16384; larger clouds re-read them from memory
+
+__device__ __forceinline__ long long di_block_min(long long v, long long *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long w = __shfl_xor(v, o); v = w < v ? w : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long m = sh[0];
+#pragma unroll
+    for (int w = 1; w < DI_THREADS / 64; ++w) m = sh[w] < m ? sh[w] : m;
+    return m;
+}
+__device__ __forceinline__ int di_block_sum(int v, int *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int m = 0;
+#pragma unroll
+    for (int w = 0; w < DI_THREADS / 64; ++w) m += sh[w];
+    return m;
+}
+
+// grid B: uniq[b][0..tcount[b]) ascending, ucnt[b][i] points per value
+__global__ __launch_bounds__(DI_THREADS) void p2n_di_peel_kernel(const long long *__restrict__ labels, int N, int maxi,
+                                                                long long *__restrict__ uniq, int *__restrict__ ucnt,
+                                                                int *__restrict__ tcount, int *__restrict__ overflow) {
+    __shared__ long long shm[DI_THREADS / 64];
+    __shared__ int shs[DI_THREADS / 64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const long long *L = labels + (long)b * N;
+    const long long NONE = 0x7fffffffffffffffLL;
+    const bool inreg = N <= DI_THREADS * DI_PER_THREAD;
+    long long r[DI_PER_THREAD];
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < DI_PER_THREAD; ++i) r[i] = t + i * DI_THREADS < N ? L[t + i * DI_THREADS] : NONE;
+    }
+    // first value: the minimum (a label equal to INT64_MAX would be taken for "none": rejected below as overflow)
+    long long cur;
+    {
+        long long m = NONE;
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < DI_PER_THREAD; ++i) m = r[i] < m ? r[i] : m;
+        } else {
+            for (int i = t; i < N; i += DI_THREADS) m = L[i] < m ? L[i] : m;
+        }
+        cur = di_block_min(m, shm);
+    }
+    int n = 0;
+    while (cur != NONE) {
+        if (n >= maxi) { if (t == 0) *overflow = 1; break; }
+        long long nx = NONE;
+        int c = 0;
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < DI_PER_THREAD; ++i) {
+                c += r[i] == cur ? 1 : 0;
+                nx = (r[i] > cur && r[i] < nx) ? r[i] : nx;
+            }
+        } else {
+            for (int i = t; i < N; i += DI_THREADS) {
+                const long long v = L[i];
+                c += v == cur ? 1 : 0;
+                nx = (v > cur && v < nx) ? v : nx;
+            }
+        }
+        c = di_block_sum(c, shs);
+        nx = di_block_min(nx, shm);
+        if (t == 0) { uniq[(long)b * maxi + n] = cur; ucnt[(long)b * maxi + n] = c; }
+        ++n;
+        cur = nx;
+    }
+    if (t == 0) {
+        tcount[b] = n;
+        int seen = 0;   // a label equal to INT64_MAX hides behind the sentinel: the counts then do not add up
+        for (int i = 0; i < n; ++i) seen += ucnt[(long)b * maxi + i];
+        if (seen != N && n < maxi) *overflow = 1;
+    }
+}
+
+// one block: cstart = exclusive prefix of tcount; then cnt / bg compacted in (cloud, label) order
+__global__ __launch_bounds__(256) void p2n_di_compact_kernel(const long long *__restrict__ uniq, const int *__restrict__ ucnt,
+                                                            const int *__restrict__ tcount, int B, int maxi,
+                                                            int *__restrict__ cstart, int *__restrict__ cnt, int *__restrict__ bg) {
+    __shared__ int base_sh;
+    if (threadIdx.x == 0) base_sh = 0;
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        const int base = base_sh, n = tcount[b];
+        for (int i = threadIdx.x; i < n; i += 256) {
+            cnt[base + i] = ucnt[(long)b * maxi + i];
+            bg[base + i] = uniq[(long)b * maxi + i] == 0 ? 1 : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { cstart[b] = base; base_sh = base + n; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cstart[B] = base_sh;
+}
+
+// per point: position of its label among its cloud's distinct values
+__global__ __launch_bounds__(256) void p2n_di_rank_kernel(const long long *__restrict__ labels, int N, long total, int maxi,
+                                                         const long long *__restrict__ uniq, const int *__restrict__ tcount,
+                                                         const int *__restrict__ cstart, int *__restrict__ inst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / N);
+    const long long v = labels[i];
+    const long long *u = uniq + (long)b * maxi;
+    int lo = 0, hi = tcount[b] - 1;
+    while (lo < hi) {   // first position with u[pos] >= v (v is present unless the cloud overflowed)
+        const int mid = (lo + hi) >> 1;
+        if (u[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    inst[i] = cstart[b] + lo;
+}
+
+extern "C" size_t p2n_dense_instances_workspace_bytes(int B, int max_per_cloud) {
+    if (B < 1 || max_per_cloud < 1) return 0;
+    return (size_t)B * max_per_cloud * (sizeof(long long) + sizeof(int)) + sizeof(int) * (size_t)B + 256;
+}
+
+// labels (B,N) int64 -> inst (B*N), cnt / bg (capacity B*max_per_cloud each; the first cstart[B] entries are written),
+// cstart (B+1), overflow (1 int, set to 1 when a cloud has more than max_per_cloud distinct labels or a label equal
+// to INT64_MAX: the outputs are then unusable).  All outputs on the device; the caller reads cstart[B] and overflow.
+extern "C" int p2n_dense_instances(const long long *labels, int B, int N, int max_per_cloud, int32_t *inst, int32_t *cnt,
+                                   int32_t *bg, int32_t *cstart, int32_t *overflow, void *workspace,
+                                   size_t workspace_bytes, void *stream_) {
+    P2N_REQUIRE(B >= 1 && N >= 1 && max_per_cloud >= 1, "p2n_dense_instances: bad shape B=%d N=%d max=%d", B, N, max_per_cloud);
+    P2N_REQUIRE(labels && inst && cnt && bg && cstart && overflow, "p2n_dense_instances: null pointer");
+    const size_t need = p2n_dense_instances_workspace_bytes(B, max_per_cloud);
+    if (!workspace || workspace_bytes < need) {
+        p2n_set_error("p2n_dense_instances: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return P2N_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    long long *uniq = (long long *)workspace;
+    int *ucnt = (int *)(uniq + (size_t)B * max_per_cloud);
+    int *tcount = ucnt + (size_t)B * max_per_cloud;
+    P2N_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int), s));
+    hipLaunchKernelGGL(p2n_di_peel_kernel, dim3(B), dim3(DI_THREADS), 0, s, labels, N, max_per_cloud, uniq, ucnt, tcount, overflow);
+    hipLaunchKernelGGL(p2n_di_compact_kernel, dim3(1), dim3(256), 0, s, uniq, ucnt, tcount, B, max_per_cloud, cstart, cnt, bg);
+    const long total = (long)B * N;
+    hipLaunchKernelGGL(p2n_di_rank_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, labels, N, total, max_per_cloud,
+                       uniq, tcount, cstart, inst);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+// out = g[0]*a + g[1]*b + g[2]*c, the three weights read on the device (the backward of the loss: upstream gradients
+// of pull / push / smoothness times their stored embedding gradients, one pass instead of five)
+__global__ __launch_bounds__(256) void p2n_combine3_kernel(const float *__restrict__ g, const float *__restrict__ a,
+                                                          const float *__restrict__ b, const float *__restrict__ c,
+                                                          long n4, float *__restrict__ out) {
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i], y = reinterpret_cast<const f32x4 *>(b)[i],
+                    z = reinterpret_cast<const f32x4 *>(c)[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (g0 * x[j] + g1 * y[j]) + g2 * z[j];   // torch's order: (g0*a + g1*b) + g2*c, no fma
+        reinterpret_cast<f32x4 *>(out)[i] = o;
+    }
+}
+
+extern "C" int p2n_combine3(const float *g3, const float *a, const float *b, const float *c, long n, float *out, void *stream_) {
+    P2N_REQUIRE(g3 && a && b && c && out && n >= 0, "p2n_combine3: null pointer");
+    P2N_REQUIRE(n % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0,
+                "p2n_combine3: n must be a multiple of 4 and the arrays 16-byte aligned");
+    if (n == 0) return P2N_OK;
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(p2n_combine3_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream_, g3, a, b, c, n / 4, out);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}

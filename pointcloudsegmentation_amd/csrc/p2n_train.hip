@@ -70,27 +70,49 @@ __device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *
 }
 
 // Raw operand fetch of k-tile kt for this lane's point (no arithmetic: the loads are queued
-// before the MFMAs of the previous tile and consumed after them).
-template <int MODE>
+// before the MFMAs of the previous tile and consumed after them).  EVERY load is unconditional -- a conditional load
+// (`ok ? p[i] : 0`) ends in a select that the compiler places behind an s_waitcnt right where the load was issued,
+// which serialises the sixteen loads of a tile in front of the MFMAs they were meant to hide behind.  Rows past K
+// are read from the last real row(s) instead: the weight image is zero there, and so is the BatchNorm table, so
+// whatever finite value arrives contributes nothing.  Channel-major operands have Ppad columns in memory, all finite
+// (every producer writes its pad columns); point-major ones are clamped to the last point.
+template <int MODE, bool k4>
 __device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bool valid, int h, f32x16 &r0, f32x16 &r1) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int k0 = 32 * kt + 8 * g + 4 * h;
+        if (MODE == LD_X || MODE == LD_EMBGRAD) {   // point-major rows (P, ld)
+            const long pc = pg < A.P ? pg : A.P - 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = valid && k0 + j < A.K;
-            if (MODE == LD_X || MODE == LD_EMBGRAD) {
-                r0[4 * g + j] = ok ? A.in0[pg * A.ld + k0 + j] : 0.f;
-            } else {
-                r0[4 * g + j] = ok ? A.in0[(long)(k0 + j) * A.Ppad + pg] : 0.f;
-                if (MODE == LD_BNBWD) r1[4 * g + j] = ok ? A.in1[(long)(k0 + j) * A.Ppad + pg] : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j < A.K ? k0 + j : A.K - 1;
+                r0[4 * g + j] = A.in0[pc * A.ld + k];
+            }
+        } else if (k4) {
+            const int kc = k0 < A.K ? k0 : A.K - 4;
+            const float *p0 = A.in0 + (long)kc * A.Ppad + pg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r0[4 * g + j] = p0[(long)j * A.Ppad];
+            if (MODE == LD_BNBWD) {
+                const float *p1 = A.in1 + (long)kc * A.Ppad + pg;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r1[4 * g + j] = p1[(long)j * A.Ppad];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j < A.K ? k0 + j : A.K - 1;
+                r0[4 * g + j] = A.in0[(long)k * A.Ppad + pg];
+                if (MODE == LD_BNBWD) r1[4 * g + j] = A.in1[(long)k * A.Ppad + pg];
             }
         }
     }
 }
 
 // The fused elementwise work: BatchNorm+ReLU forward, or the whole BatchNorm/ReLU backward
-// dz = A1*dy + A2 + A3*z with dy = da masked by relu(bn(z)) > 0.  tab = per-k constants in LDS.
+// dz = A1*dy + A2 + A3*z with dy = da masked by relu(bn(z)) > 0.  tab = per-k constants in LDS, zero for k >= K, and
+// the fetch delivered zeros there: those rows come out as zero without a test (relu(0*0+0) = 0; 0*0 + (0*0 + 0) = 0).
+// Pad columns (p >= P) come out finite and are never read by a reduction.
 template <int MODE>
 __device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool valid, int h, const float *tab, int KP,
                                                const f32x16 &r0, const f32x16 &r1) {
@@ -109,30 +131,35 @@ __device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v = 0.f;
-            if (valid && k0 + j < A.K) {
-                if (MODE == LD_BNRELU) {
-                    v = fmaxf(fmaf(r0[4 * g + j], s[j], t[j]), 0.f);
-                } else {
-                    const float z = r1[4 * g + j], da = r0[4 * g + j];
-                    const float dy = fmaf(z, s[j], t[j]) > 0.f ? da : 0.f;
-                    v = fmaf(a3[j], z, fmaf(a1[j], dy, a2[j]));
-                }
+            if (MODE == LD_BNRELU) {
+                out[4 * g + j] = fmaxf(fmaf(r0[4 * g + j], s[j], t[j]), 0.f);
+            } else {
+                const float z = r1[4 * g + j], da = r0[4 * g + j];
+                const float dy = fmaf(z, s[j], t[j]) > 0.f ? da : 0.f;
+                out[4 * g + j] = fmaf(a3[j], z, fmaf(a1[j], dy, a2[j]));
             }
-            out[4 * g + j] = v;
         }
     }
     return out;
 }
 
 // dz of k-tile kt back over da (same rows, this lane's column): every element was read by this lane only
+template <bool k4>
 __device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg, int h, const f32x16 &v) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int k0 = 32 * kt + 8 * g + 4 * h;
+        if (k4) {
+            if (k0 < A.K) {
+                float *d = A.dz_out + (long)k0 * A.Ppad + pg;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k0 + j < A.K) A.dz_out[(long)(k0 + j) * A.Ppad + pg] = v[4 * g + j];
+                for (int j = 0; j < 4; ++j) d[(long)j * A.Ppad] = v[4 * g + j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < A.K) A.dz_out[(long)(k0 + j) * A.Ppad + pg] = v[4 * g + j];
+        }
     }
 }
 
@@ -140,7 +167,9 @@ __device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg,
 // by k-tile: while the CT*16 MFMAs of tile kt execute, the operands of tile kt+1 are already
 // in flight (fetched raw, transformed after the MFMAs), and the weights of the next chunk land
 // in the other LDS buffer by LDS-DMA (chunk = 32 fragments = 8/CT k-tiles).
-template <int MODE, int CT, bool OUT_PM>
+// K4: the reduction length is a multiple of four (every layer of the model; only first layers of hierarchical levels
+// are not), so the row bound is tested per group of four rows.
+template <int MODE, int CT, bool OUT_PM, bool K4>
 __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
     __shared__ __attribute__((aligned(16))) float wbuf[2 * TL_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float tab[5 * 256];
@@ -151,6 +180,8 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
     const bool valid = pg < A.P;
     const int KT = A.KT, KP = KT * 32;
     tl_stage(A.wimg, wbuf, 0, wave, lane);   // first weight chunk flies while the operands load
+    __shared__ __attribute__((aligned(16))) float bias_s[256];   // the epilogue's bias, zero without one
+    if (threadIdx.x < CT * 32) bias_s[threadIdx.x] = (A.bias && (int)threadIdx.x < A.rows) ? A.bias[threadIdx.x] : 0.f;
     if (MODE == LD_BNRELU || MODE == LD_BNBWD) {
         const int nt = (MODE == LD_BNRELU ? 2 : 5);
         for (int i = threadIdx.x; i < nt * KP; i += 256) {
@@ -159,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
         }
     }
     f32x16 r0, r1;
-    tl_fetch<MODE>(A, 0, pg, valid, h, r0, r1);
+    tl_fetch<MODE, K4>(A, 0, pg, valid, h, r0, r1);
     f32x16 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -167,14 +198,14 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
         for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
     p2n_dma_barrier();   // tab visible (and chunk 0 landed)
     f32x16 cur = tl_transform<MODE>(A, 0, valid, h, tab, KP, r0, r1);
-    if (MODE == LD_BNBWD && A.dz_out) tl_store_dz(A, 0, pg, h, cur);
+    if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4>(A, 0, pg, h, cur);
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         if (kt % KPC == 0) {
             if (kt) p2n_dma_barrier();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
             tl_stage(A.wimg, wbuf, kt / KPC + 1, wave, lane);
         }
-        if (kt + 1 < KT) tl_fetch<MODE>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
+        if (kt + 1 < KT) tl_fetch<MODE, K4>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
         const float *wb = wbuf + ((kt / KPC) & 1) * TL_CHUNK_FLOATS + (kt % KPC) * (CT * 4 * 256) + lane * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -188,35 +219,58 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
         }
         if (kt + 1 < KT) {
             cur = tl_transform<MODE>(A, kt + 1, valid, h, tab, KP, r0, r1);
-            if (MODE == LD_BNBWD && A.dz_out) tl_store_dz(A, kt + 1, pg, h, cur);
+            if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4>(A, kt + 1, pg, h, cur);
         }
     }
     const int cloud = valid ? (int)(pg / A.N) : 0;
+    // Epilogue.  Row counts that are multiples of four (every layer of the model but an odd embedding size) take
+    // whole groups of four rows: one test, one 16-byte bias read from LDS, one 16-byte read of the per-cloud bias,
+    // four stores -- written per element with its own bound test, bias load and wait, the epilogue cost 0.38 ms
+    // of the 1.78 ms forward.
+    if ((A.rows & 3) == 0 && (!OUT_PM || ((A.ld & 3) == 0 && ((uintptr_t)A.out & 15) == 0)) &&
+        (!A.bias_cloud || ((uintptr_t)A.bias_cloud & 15) == 0)) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        if (32 * ct >= A.rows) break;
+        for (int ct = 0; ct < CT; ++ct) {
+            if (32 * ct >= A.rows) continue;   // wave-uniform
+            f32x4 cv[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r0i = 32 * ct + 8 * g + 4 * h;
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = acc[ct][4 * g + j];
-                if (r0i + j < A.rows) {
-                    if (A.bias) v += A.bias[r0i + j];
-                    if (A.bias_cloud) v += A.bias_cloud[(long)cloud * A.rows + r0i + j];
-                }
-                o[j] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int r0i = 32 * ct + 8 * g + 4 * h;
+                cv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (A.bias_cloud && r0i < A.rows) cv[g] = *reinterpret_cast<const f32x4 *>(A.bias_cloud + (long)cloud * A.rows + r0i);
             }
-            if (OUT_PM) {
-                if (valid)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (r0i + j < A.rows) A.out[pg * A.ld + r0i + j] = o[j];
-            } else {
+            for (int g = 0; g < 4; ++g) {
+                const int r0i = 32 * ct + 8 * g + 4 * h;
+                if (r0i >= A.rows) continue;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bias_s[r0i]);
+                f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (r0i + j < A.rows) A.out[(long)(r0i + j) * A.Ppad + pg] = o[j];   // pad columns too (finite)
+                for (int j = 0; j < 4; ++j) o[j] = (acc[ct][4 * g + j] + bv[j]) + cv[g][j];
+                if (OUT_PM) {
+                    if (valid) *reinterpret_cast<f32x4 *>(A.out + pg * A.ld + r0i) = o;
+                } else {
+                    float *dst = A.out + (long)r0i * A.Ppad + pg;   // pad columns too (finite)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[(long)j * A.Ppad] = o[j];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if (32 * ct >= A.rows) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0i = 32 * ct + 8 * g + 4 * h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (r0i + j >= A.rows) continue;
+                    float v = acc[ct][4 * g + j] + bias_s[r0i + j];
+                    if (A.bias_cloud) v += A.bias_cloud[(long)cloud * A.rows + r0i + j];
+                    if (OUT_PM) { if (valid) A.out[pg * A.ld + r0i + j] = v; }
+                    else A.out[(long)(r0i + j) * A.Ppad + pg] = v;
+                }
             }
         }
     }
@@ -742,11 +796,20 @@ int launch_layer(LayerArgs a, hipStream_t s) {
     const dim3 grid(a.Ppad / 128), blk(256);
     a.KT = (a.K + 31) / 32;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_GEMM, s);
-    switch (ct_pad(a.rows)) {
-        case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM>), grid, blk, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM>), grid, blk, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM>), grid, blk, 0, s, a); break;
-        default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM>), grid, blk, 0, s, a); break;
+    if (a.K % 4 == 0) {
+        switch (ct_pad(a.rows)) {
+            case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM, true>), grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM, true>), grid, blk, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM, true>), grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM, true>), grid, blk, 0, s, a); break;
+        }
+    } else {
+        switch (ct_pad(a.rows)) {
+            case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM, false>), grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM, false>), grid, blk, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM, false>), grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM, false>), grid, blk, 0, s, a); break;
+        }
     }
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
@@ -891,7 +954,31 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
         }
     }
     hipStream_t s = (hipStream_t)stream_;
-    for (int l = 0; l < 9; ++l) P2N_CHECK_HIP(hipMemsetAsync(dW[l], 0, sizeof(float) * (size_t)n.cin[l] * n.cout[l], s));
+    {
+        // the weight gradients are accumulated with atomics and start from zero.  When all 34 gradient tensors are
+        // views of one flat bucket (pointcloudsegmentation_amd/train.py hands them out that way, 256-byte aligned)
+        // one fill covers it -- everything else in the span is fully overwritten later in this call -- instead of nine.
+        uintptr_t lo = ~(uintptr_t)0, hi = 0;
+        size_t sum = 0;
+        int ng = 0;
+        for (int l = 0; l < 9; ++l) {
+            const size_t sz[4] = {sizeof(float) * (size_t)n.cin[l] * n.cout[l], sizeof(float) * (size_t)n.cout[l],
+                                  sizeof(float) * (size_t)n.cout[l], sizeof(float) * (size_t)n.cout[l]};
+            float *ptr[4] = {dW[l], db[l], dgam[l], dbet[l]};
+            for (int i = 0; i < (l < 8 ? 4 : 2); ++i) {
+                const uintptr_t a = (uintptr_t)ptr[i];
+                lo = a < lo ? a : lo;
+                hi = a + sz[i] > hi ? a + sz[i] : hi;
+                sum += sz[i];
+                ++ng;
+            }
+        }
+        if (hi - lo <= sum + (size_t)ng * 256) {
+            P2N_CHECK_HIP(hipMemsetAsync((void *)lo, 0, hi - lo, s));
+        } else {
+            for (int l = 0; l < 9; ++l) P2N_CHECK_HIP(hipMemsetAsync(dW[l], 0, sizeof(float) * (size_t)n.cin[l] * n.cout[l], s));
+        }
+    }
 
     // ---- layer 8 (no BN): dz8 = gemb
     if (256 % E == 0) {

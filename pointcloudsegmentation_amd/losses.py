@@ -18,20 +18,48 @@ from . import _lib
 from . import runtime as _rt
 
 
+_MAX_LABELS_PER_CLOUD = 1024
+
+
 def _dense_instances(labels: torch.Tensor):
     """Integer plumbing for the HIP kernels: (B,N) labels -> dense ids per (cloud,label)
-    in ascending (cloud,label) order, counts, background flags, per-cloud id ranges."""
+    in ascending (cloud,label) order, counts, background flags, per-cloud id ranges.
+    p2n_dense_instances does it in three launches (one workgroup per cloud peels off the distinct labels in
+    ascending order); clouds with more than 1024 distinct labels take the torch.unique route below."""
     B, N = labels.shape
-    lab = labels.to(torch.int64)
-    lo = lab.min()
-    span = (lab.max() - lo + 1)
-    key = (torch.arange(B, device=lab.device).unsqueeze(1) * span + (lab - lo)).reshape(-1)
-    uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
-    cloud = torch.div(uniq, span, rounding_mode="floor")
-    bg = ((uniq - cloud * span + lo) == 0)
-    cstart = torch.searchsorted(cloud, torch.arange(B + 1, device=lab.device))
-    return (inv.to(torch.int32).contiguous(), cnt.to(torch.int32).contiguous(), bg.to(torch.int32).contiguous(),
-            cstart.to(torch.int32).contiguous(), int(uniq.numel()))
+    lab = labels.to(torch.int64).contiguous()
+    L = _lib.lib()
+    dev = lab.device
+    cap = B * _MAX_LABELS_PER_CLOUD
+    inst = torch.empty(B * N, dtype=torch.int32, device=dev)
+    meta = torch.empty(2 * cap + B + 2, dtype=torch.int32, device=dev)     # cnt | bg | cstart (B+1) | overflow
+    cnt, bg, cstart, over = meta[:cap], meta[cap:2 * cap], meta[2 * cap:2 * cap + B + 1], meta[2 * cap + B + 1:]
+    ws = _rt.workspace(L.p2n_dense_instances_workspace_bytes(B, _MAX_LABELS_PER_CLOUD), dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.p2n_dense_instances(lab.data_ptr(), B, N, _MAX_LABELS_PER_CLOUD, inst.data_ptr(), cnt.data_ptr(),
+                                         bg.data_ptr(), cstart.data_ptr(), over.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _rt.stream_handle(dev)), "p2n_dense_instances")
+    tail = meta[2 * cap + B:].cpu()                 # {cstart[B] = number of instances, overflow}: the one host read
+    if int(tail[1]) == 0:
+        T = int(tail[0])
+        return inst, cnt[:T], bg[:T], cstart, T
+    return _dense_instances_torch(lab)
+
+
+def _dense_instances_torch(lab: torch.Tensor):
+    """the same through torch.unique per cloud, as reference losses.py:389-395 enumerates the instances (any label
+    values, any number of them); only clouds with more than 1024 distinct labels come here"""
+    B, N = lab.shape
+    inst, cnt, bg, cstart, base = [], [], [], [0], 0
+    for b in range(B):
+        uniq, inv, c = torch.unique(lab[b], return_inverse=True, return_counts=True)
+        inst.append(inv + base)
+        cnt.append(c)
+        bg.append(uniq == 0)
+        base += int(uniq.numel())
+        cstart.append(base)
+    return (torch.cat(inst).to(torch.int32).contiguous(), torch.cat(cnt).to(torch.int32).contiguous(),
+            torch.cat(bg).to(torch.int32).contiguous(), torch.tensor(cstart, dtype=torch.int32, device=lab.device), base)
 
 
 class _InstanceSegLossFn(torch.autograd.Function):
@@ -71,7 +99,15 @@ class _InstanceSegLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dp, dq, ds = ctx.saved_tensors
-        return None, g[0] * dp + g[1] * dq + g[2] * ds, None, None, None, None
+        g = g.to(torch.float32).contiguous()
+        out = torch.empty_like(dp)
+        n = out.numel()
+        if n % 4 or not g.is_cuda:
+            return None, g[0] * dp + g[1] * dq + g[2] * ds, None, None, None, None
+        with torch.cuda.device(out.device):          # (g0*dp + g1*dq) + g2*ds in one pass, weights read on the device
+            _lib.check(_lib.lib().p2n_combine3(g.data_ptr(), dp.data_ptr(), dq.data_ptr(), ds.data_ptr(), n, out.data_ptr(),
+                                               _rt.stream_handle(out.device)), "p2n_combine3")
+        return None, out, None, None, None, None
 
 
 class DiscriminativeLoss(nn.Module):

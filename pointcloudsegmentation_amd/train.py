@@ -116,8 +116,7 @@ def forward_train(model, x):
         return _Point2NetTrainFn.apply(x, model, -1.0, True, *learnables)   # momentum < 0: the library's eval-statistics mode
     emb = _Point2NetTrainFn.apply(x, model, momentum, True, *learnables)
     with torch.no_grad():
-        for m in bns:
-            m.num_batches_tracked += 1
+        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)      # one launch instead of eight
     # the kernels updated running_mean/var through raw pointers (no version bump): the eval-mode packed
     # images built from the old statistics must not be reused
     model._cache.key = None

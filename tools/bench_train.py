@@ -45,7 +45,8 @@ def main():
     torch.manual_seed(0)
     model = Point2Net(6, 64).to(dev).train()
     crit = InstanceSegLoss(64, 0.1, 0.5)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5)      # reference train.py:84-88
+    # reference train.py:84-88 (Adam, lr 1e-4, weight_decay 1e-5); fused=True is torch's single-kernel implementation of it
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
     x = torch.from_numpy(make_batch(b, args.points, seed=200 + rank)).to(dev)
     y = torch.from_numpy(make_labels(b, args.points, seed=rank)).to(dev)
     pts = x[:, :, :3].contiguous()

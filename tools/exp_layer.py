@@ -1,0 +1,26 @@
+"""Timing experiments on the training GEMM kernels (P2N_TL_EXP switches parts of p2n_train_layer_kernel off:
+1 operand fetch, 2 operand transform, 4 epilogue, 8 weight restaging + barriers; results are then invalid)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pointcloudsegmentation_amd import _lib
+from pointcloudsegmentation_amd.synth import make_batch
+from src.models.point2net import Point2Net
+torch.manual_seed(0)
+m = Point2Net(6, 64).cuda().train()
+x = torch.from_numpy(make_batch(32, 8192, seed=200)).cuda()
+L = _lib.lib()
+def run(bwd):
+    e = m(x)
+    if bwd:
+        e.sum().backward()
+for bwd in (False, True):
+    for _ in range(2):
+        run(bwd)
+    torch.cuda.synchronize()
+    L.p2n_profile_select(-1); L.p2n_profile_enable(1)
+    for _ in range(5):
+        run(bwd)
+    ms = (ctypes.c_float * 32)(); cnt = (ctypes.c_int * 32)()
+    L.p2n_profile_collect(32, ms, cnt); L.p2n_profile_enable(0)
+    print("P2N_TL_EXP=%s %s: layer GEMMs %.3f ms (%d launches), wgrad %.3f ms" % (os.environ.get("P2N_TL_EXP", "0"), "fwd+bwd" if bwd else "fwd", ms[8] / 5, cnt[8] / 5, ms[9] / 5))
