@@ -376,13 +376,15 @@ __device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__res
 // RT x CT MFMA tiles per wave: the workgroup's block of dW is (64 RT) x (64 CT).  128 x 128 blocks
 // halve the operand re-reads of the big layers (the 64 x 64 version was bound by L2/HBM traffic).
 template <int AMODE, int BMODE, int RT, int CT>
-__global__ __launch_bounds__(256) void p2n_wgrad_kernel(WgArgs A) {
+__global__ __launch_bounds__(256, 2) void p2n_wgrad_kernel(WgArgs A) {   // two workgroups per CU: one parks its next block while the other multiplies
     __shared__ __attribute__((aligned(16))) float sa[RT * WG_TILE * WG_LD], sb[CT * WG_TILE * WG_LD];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int r = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int br = blockIdx.y / A.ntc, bc = blockIdx.y % A.ntc;
-    const long s0 = (long)blockIdx.x * A.slice;
+    // blockIdx.x = tile of dW (fastest), blockIdx.y = slice of points: the workgroups that read the same slice of the
+    // operands are dispatched together, so all but the first find it in the shared cache levels instead of HBM
+    const int br = blockIdx.x / A.ntc, bc = blockIdx.x % A.ntc;
+    const long s0 = (long)blockIdx.y * A.slice;
     long s1 = s0 + A.slice;
     if (s1 > A.P) s1 = A.P;
     f32x16 acc[RT][CT];
@@ -833,7 +835,7 @@ int launch_wgrad_rc(WgArgs a, hipStream_t s) {
     a.slice = wgrad_slice(a.P, ntr * a.ntc);
     const long nsl = ((long)a.P + a.slice - 1) / a.slice;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_WGRAD, s);
-    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM, RT, CT>), dim3((unsigned)nsl, ntr * a.ntc), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM, RT, CT>), dim3(ntr * a.ntc, (unsigned)nsl), dim3(256), 0, s, a);
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
