@@ -81,6 +81,37 @@ __device__ __forceinline__ void p2n_dma_barrier() {
     __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8) | (0 << 14));   // vmcnt(0) lgkmcnt(0)
     __syncthreads();
 }
+
+// Channel maxima of one 32x32 tile over the 32 lanes of each wave half (one centroid's 32 neighbours), as a
+// halving transpose-reduce: at every step lanes pair up inside their 16-lane DPP row (xor 1, xor 2, rotate
+// 4, rotate 8), each lane keeps one register of a pair and takes the partner's copy of it, so 16 registers
+// shrink to 8, 4, 2, 1 with 15 exchanges instead of 64; one ds_swizzle (lane ^ 16, no memory access) then
+// joins the two rows of the half.  Lane i of a row ends up with the maximum of register i, i.e. of channel
+// 32ct + 8(i>>2) + 4h + (i&3).  Values are post-ReLU (>= 0, or -0.0): their bit patterns order as signed
+// integers, and integer max folds the DPP operand into the instruction.
+template <int N, int CTRL>
+__device__ __forceinline__ void p2n_halve_max(int (&m)[16], bool upper) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int keep = upper ? m[2 * q + 1] : m[2 * q];
+        const int give = upper ? m[2 * q] : m[2 * q + 1];
+        const int t = __builtin_amdgcn_update_dpp(0, give, CTRL, 0xF, 0xF, true);
+        m[q] = keep > t ? keep : t;
+    }
+}
+
+__device__ __forceinline__ float p2n_tile_half_max(const f32x16 v, int lane) {
+    int m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = __float_as_int(v[i]);
+    p2n_halve_max<8, 0xB1>(m, lane & 1);    // quad_perm [1,0,3,2]
+    p2n_halve_max<4, 0x4E>(m, lane & 2);    // quad_perm [2,3,0,1]
+    p2n_halve_max<2, 0x124>(m, lane & 4);   // row_ror:4
+    p2n_halve_max<1, 0x128>(m, lane & 8);   // row_ror:8
+    const int t = __builtin_amdgcn_ds_swizzle(m[0], 0x401F);   // bit mode: and 0x1F, or 0, xor 0x10
+    return __int_as_float(m[0] > t ? m[0] : t);
+}
+
 #endif
 
 // ---- optional per-kernel timing (p2n_api.hip) ----

@@ -314,16 +314,16 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
                 f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
                 *reinterpret_cast<f32x4 *>(sp + (ct * 4 + g) * P2N_FRAG_FLOATS) = o;
             }
-            // channel max over the workgroup's points: post-ReLU values are >= 0, so their bit
-            // patterns order as unsigned integers and 0 is the neutral element for masked
-            // points.  DPP max inside each 16-lane row, then one LDS atomic per row.
+            // channel max over the workgroup's points: post-ReLU values are >= 0, so their bit patterns order as
+            // integers and 0 is the neutral element for masked points.  Halving transpose-reduce over the 32 lanes
+            // of each wave half (15 DPP maxima + one swizzle per tile, p2n_common.h; 16 x four DPP steps before),
+            // after which lane i of a row holds the maximum of register i: one LDS atomic per tile.
+            f32x16 vm;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned m = row_max_u32(valid ? __float_as_uint(v[4 * g + j]) : 0u);
-                    if ((lane & 15) == 0) atomicMax(&smax[32 * ct + 8 * g + 4 * h + j], m);
-                }
+            for (int i = 0; i < 16; ++i) vm[i] = valid ? v[i] : 0.f;
+            const int mx = __float_as_int(p2n_tile_half_max(vm, lane));
+            if ((lane & 16) == 0)
+                atomicMax(&smax[32 * ct + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3)], (unsigned)(mx > 0 ? mx : 0));   // (-0.0 -> 0)
         }
     }
     p2n_dma_barrier();   // also drains the spare chunk's DMA before the workgroup's LDS is released
