@@ -538,58 +538,104 @@ class Point2NetSA(nn.Module):
             u1 = self.fp2.forward_rows(xyz1, xyz2, f1, f1.shape[2], 0, f1.shape[2], u2)
             emb = self.fp1.forward_rows(xyz0, xyz1, x, F, 3, c, u1, head=self.head)   # (B,N,E)
         else:
-            s_fps, s_search, s_nn = _geometry_streams(dev)
-            sas = (self.sa1, self.sa2, self.sa3)
             start = torch.cuda.Event()
             start.record(main)
-            for st in (s_fps, s_search, s_nn):
-                xyz0.record_stream(st)
-            xyz, cent = [xyz0], []
-            with torch.cuda.stream(s_fps):                   # fps1 -> fps2 -> fps3, nothing in between
-                s_fps.wait_event(start)
-                for sa in sas:
-                    M = max(1, xyz[-1].shape[1] // sa.npoint_div)
-                    nx = gather_xyz(xyz[-1], 3, ops.farthest_point_sample(xyz[-1], M))
-                    ev = torch.cuda.Event()
-                    ev.record(s_fps)
-                    xyz.append(nx)
-                    cent.append(ev)
-            with torch.cuda.stream(s_nn):                    # the largest search (fine points x level-1 centroids)
-                s_nn.wait_event(cent[0])
-                nn01 = ops.three_nn(xyz[0], xyz[1])[1:]
-                e_nn01 = torch.cuda.Event()
-                e_nn01.record(s_nn)
-            groups, e_ball = [], []
-            with torch.cuda.stream(s_search):
-                for l, sa in enumerate(sas):
-                    s_search.wait_event(cent[l])
-                    groups.append(ops.ball_query(xyz[l], xyz[l + 1], sa.radius, sa.nsample))
-                    ev = torch.cuda.Event()
-                    ev.record(s_search)
-                    e_ball.append(ev)
-                nn23 = ops.three_nn(xyz[2], xyz[3])[1:]
-                nn12 = ops.three_nn(xyz[1], xyz[2])[1:]
-                e_nn = torch.cuda.Event()
-                e_nn.record(s_search)
-            for t in xyz[1:] + groups + list(nn01) + list(nn12) + list(nn23):
-                t.record_stream(main)                        # allocated on a side stream, consumed on this one
-            xyz[1].record_stream(s_nn)
-            for t in xyz[1:]:
-                t.record_stream(s_search)
-            main.wait_event(e_ball[0])
-            _, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c, geometry=(xyz[1], groups[0]))
-            main.wait_event(e_ball[1])
-            _, f2 = self.sa2.forward_rows(xyz[1], f1, f1.shape[2], 0, f1.shape[2], geometry=(xyz[2], groups[1]))
-            main.wait_event(e_ball[2])
-            _, f3 = self.sa3.forward_rows(xyz[2], f2, f2.shape[2], 0, f2.shape[2], geometry=(xyz[3], groups[2]))
-            main.wait_event(e_nn)
-            u2 = self.fp3.forward_rows(xyz[2], xyz[3], f2, f2.shape[2], 0, f2.shape[2], f3, neighbours=nn23)
-            u1 = self.fp2.forward_rows(xyz[1], xyz[2], f1, f1.shape[2], 0, f1.shape[2], u2, neighbours=nn12)
-            main.wait_event(e_nn01)
-            emb = self.fp1.forward_rows(xyz0, xyz[1], x, F, 3, c, u1, head=self.head, neighbours=nn01)
+            emb = self._levels(x, xyz0, self._geometry(xyz0, start))
         if ops.fps_needs_check(x.shape[0], x.shape[1]):
             ops.fps_check(x.device)      # clouds sampled by workgroup clusters: a timed-out exchange raises here
         return emb
+
+
+    def _geometry(self, xyz0, start):
+        """Everything that depends on coordinates only, queued on the three geometry streams behind `start`:
+        centroids of the three levels (FPS chain), ball-query groups, three-NN neighbours and weights.  Returns the
+        tensors and the events the level kernels wait for."""
+        dev = xyz0.device
+        main = torch.cuda.current_stream(dev)
+        s_fps, s_search, s_nn = _geometry_streams(dev)
+        sas = (self.sa1, self.sa2, self.sa3)
+        for st in (s_fps, s_search, s_nn):
+            xyz0.record_stream(st)
+        xyz, cent = [xyz0], []
+        with torch.cuda.stream(s_fps):                   # fps1 -> fps2 -> fps3, nothing in between
+            s_fps.wait_event(start)
+            for sa in sas:
+                M = max(1, xyz[-1].shape[1] // sa.npoint_div)
+                nx = gather_xyz(xyz[-1], 3, ops.farthest_point_sample(xyz[-1], M))
+                ev = torch.cuda.Event()
+                ev.record(s_fps)
+                xyz.append(nx)
+                cent.append(ev)
+        with torch.cuda.stream(s_nn):                    # the largest search (fine points x level-1 centroids)
+            s_nn.wait_event(cent[0])
+            nn01 = ops.three_nn(xyz[0], xyz[1])[1:]
+            e_nn01 = torch.cuda.Event()
+            e_nn01.record(s_nn)
+        groups, e_ball = [], []
+        with torch.cuda.stream(s_search):
+            for l, sa in enumerate(sas):
+                s_search.wait_event(cent[l])
+                groups.append(ops.ball_query(xyz[l], xyz[l + 1], sa.radius, sa.nsample))
+                ev = torch.cuda.Event()
+                ev.record(s_search)
+                e_ball.append(ev)
+            nn23 = ops.three_nn(xyz[2], xyz[3])[1:]
+            nn12 = ops.three_nn(xyz[1], xyz[2])[1:]
+            e_nn = torch.cuda.Event()
+            e_nn.record(s_search)
+        for t in xyz[1:] + groups + list(nn01) + list(nn12) + list(nn23):
+            t.record_stream(main)                        # allocated on a side stream, consumed on the caller's
+        xyz[1].record_stream(s_nn)
+        for t in xyz[1:]:
+            t.record_stream(s_search)
+        return {"xyz": xyz, "groups": groups, "nn01": nn01, "nn12": nn12, "nn23": nn23,
+                "e_ball": e_ball, "e_nn": e_nn, "e_nn01": e_nn01}
+
+    def _levels(self, x, xyz0, geo):
+        """The six fused level kernels on the caller's stream, each behind the event of the geometry it needs."""
+        F = self.feature_dim
+        c = F - 3
+        main = torch.cuda.current_stream(x.device)
+        xyz, groups = geo["xyz"], geo["groups"]
+        main.wait_event(geo["e_ball"][0])
+        _, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c, geometry=(xyz[1], groups[0]))
+        main.wait_event(geo["e_ball"][1])
+        _, f2 = self.sa2.forward_rows(xyz[1], f1, f1.shape[2], 0, f1.shape[2], geometry=(xyz[2], groups[1]))
+        main.wait_event(geo["e_ball"][2])
+        _, f3 = self.sa3.forward_rows(xyz[2], f2, f2.shape[2], 0, f2.shape[2], geometry=(xyz[3], groups[2]))
+        main.wait_event(geo["e_nn"])
+        u2 = self.fp3.forward_rows(xyz[2], xyz[3], f2, f2.shape[2], 0, f2.shape[2], f3, neighbours=geo["nn23"])
+        u1 = self.fp2.forward_rows(xyz[1], xyz[2], f1, f1.shape[2], 0, f1.shape[2], u2, neighbours=geo["nn12"])
+        main.wait_event(geo["e_nn01"])
+        return self.fp1.forward_rows(xyz0, xyz[1], x, F, 3, c, u1, head=self.head, neighbours=geo["nn01"])
+
+    def forward_many(self, batches):
+        """Embeddings of a sequence of batches [(B,N,F), ...] already on the GPU, as a pipeline over them: the
+        sampling chain of batch i+1 (latency-bound on a few CUs, 65 % of a lone forward) runs beside the level
+        kernels of batch i.  GPU eval only (the fused path); results equal forward(batch) bit for bit."""
+        batches = list(batches)
+        if not batches:
+            return []
+        x0 = batches[0]
+        if not (x0.is_cuda and self.fused and self._fused_ok()):
+            return [self(x) for x in batches]
+        for x in batches:
+            if x.dim() != 3 or x.size(2) != self.feature_dim:
+                raise ValueError(f"expected batches of shape (B, N, {self.feature_dim}), got {tuple(x.shape)}")
+        dev = x0.device
+        main = torch.cuda.current_stream(dev)
+        xs = [_rt.require_cuda_f32(x, "x") for x in batches]
+        xyz0 = [x[:, :, :3].contiguous() for x in xs]
+        start = torch.cuda.Event()                       # every batch is resident: its geometry waits for nothing else
+        start.record(main)
+        out, geo = [], self._geometry(xyz0[0], start)
+        for i, x in enumerate(xs):
+            nxt = self._geometry(xyz0[i + 1], start) if i + 1 < len(xs) else None
+            out.append(self._levels(x, xyz0[i], geo))
+            geo = nxt
+        if any(ops.fps_needs_check(x.shape[0], x.shape[1]) for x in xs):
+            ops.fps_check(dev)
+        return out
 
 
 _geo_streams = {}

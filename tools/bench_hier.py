@@ -66,6 +66,17 @@ def run(B=16, N=8192, iters=20, unfused=False, serial=False):
             y = model(x)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / iters
+        stream_ms = None
+        if not unfused and not serial:                  # a stream of batches: FPS of batch i+1 beside the levels of batch i
+            xs = [torch.from_numpy(make_batch(B, N, seed=50 + i)).to(dev) for i in range(8)]
+            model.forward_many(xs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ys = model.forward_many(xs)
+            torch.cuda.synchronize()
+            stream_ms = 1e3 * (time.perf_counter() - t0) / (3 * len(xs))
+            assert all(bool(torch.isfinite(v).all()) for v in ys)
         L.p2n_profile_select(-1)
         L.p2n_profile_enable(1)
         for _ in range(iters):
@@ -83,6 +94,8 @@ def run(B=16, N=8192, iters=20, unfused=False, serial=False):
     return {"metric": "Point2NetSA eval forward (FPS+ball-query+MLP+3-NN), B=%d x N=%d" % (B, N),
             "path": "per-operator composition" if unfused else ("fused levels, one stream" if serial else "fused levels, geometry on side streams"),
             "ms_per_forward_wall": 1e3 * wall, "points_per_s": B * N / wall,
+            "ms_per_forward_in_a_stream_of_8_batches": stream_ms,
+            "points_per_s_in_a_stream": (B * N / (stream_ms * 1e-3)) if stream_ms else None,
             "kernels": kern, "kernel_ms_sum": sum(ms) / iters,
             "mlp": {"algorithmic_GFLOP": {k: v / 1e9 for k, v in fl.items()}, "total_GFLOP": total_fl / 1e9,
                     "ms": mlp_ms, "TFLOP_per_s": total_fl / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None,
