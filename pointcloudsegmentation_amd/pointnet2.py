@@ -546,13 +546,13 @@ class Point2NetSA(nn.Module):
         return emb
 
 
-    def _geometry(self, xyz0, start):
+    def _geometry(self, xyz0, start, lane: int = 0):
         """Everything that depends on coordinates only, queued on the three geometry streams behind `start`:
         centroids of the three levels (FPS chain), ball-query groups, three-NN neighbours and weights.  Returns the
         tensors and the events the level kernels wait for."""
         dev = xyz0.device
         main = torch.cuda.current_stream(dev)
-        s_fps, s_search, s_nn = _geometry_streams(dev)
+        s_fps, s_search, s_nn = _geometry_streams(dev, lane)
         sas = (self.sa1, self.sa2, self.sa3)
         for st in (s_fps, s_search, s_nn):
             xyz0.record_stream(st)
@@ -611,7 +611,7 @@ class Point2NetSA(nn.Module):
 
     def forward_many(self, batches):
         """Embeddings of a sequence of batches [(B,N,F), ...] already on the GPU, as a pipeline over them: the
-        sampling chain of batch i+1 (latency-bound on a few CUs, 65 % of a lone forward) runs beside the level
+        sampling chains of the next batches (latency-bound on a few CUs, 65 % of a lone forward) run beside the level
         kernels of batch i.  GPU eval only (the fused path); results equal forward(batch) bit for bit."""
         batches = list(batches)
         if not batches:
@@ -628,23 +628,28 @@ class Point2NetSA(nn.Module):
         xyz0 = [x[:, :, :3].contiguous() for x in xs]
         start = torch.cuda.Event()                       # every batch is resident: its geometry waits for nothing else
         start.record(main)
-        out, geo = [], self._geometry(xyz0[0], start)
+        # GEO_LANES sampling chains run side by side (one uses B of the 256 CUs), each on its own stream triple
+        out, geo = [], {}
+        for i in range(min(GEO_LANES, len(xs))):
+            geo[i] = self._geometry(xyz0[i], start, i % GEO_LANES)
         for i, x in enumerate(xs):
-            nxt = self._geometry(xyz0[i + 1], start) if i + 1 < len(xs) else None
-            out.append(self._levels(x, xyz0[i], geo))
-            geo = nxt
+            out.append(self._levels(x, xyz0[i], geo.pop(i)))
+            j = i + GEO_LANES
+            if j < len(xs):
+                geo[j] = self._geometry(xyz0[j], start, j % GEO_LANES)
         if any(ops.fps_needs_check(x.shape[0], x.shape[1]) for x in xs):
             ops.fps_check(dev)
         return out
 
 
 _geo_streams = {}
+GEO_LANES = 3      # geometry pipelines in flight in forward_many
 
 
-def _geometry_streams(dev: torch.device):
-    """three side streams per device (FPS chain, ball queries + small three-NN searches, the large three-NN
-    search), created once: the caching allocator keeps a pool per stream"""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+def _geometry_streams(dev: torch.device, lane: int = 0):
+    """three side streams per device and lane (FPS chain, ball queries + small three-NN searches, the large
+    three-NN search), created once: the caching allocator keeps a pool per stream"""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), lane)
     if key not in _geo_streams:
         _geo_streams[key] = tuple(torch.cuda.Stream(device=dev) for _ in range(3))
     return _geo_streams[key]
