@@ -50,7 +50,11 @@ class _PackedCache:
             self._perm = [names.index(k) for k in order]
             self._count = len(ps)
         tensors = [ps[i] for i in self._perm]
-        key = (precision,) + tuple([(t.data_ptr(), t._version) for t in tensors])
+        # the train-mode kernels update running_mean / running_var through raw pointers (no version bump); every such
+        # update increments num_batches_tracked in place, so its version stands in -- also when a sub-module (the bare
+        # encoder) was trained on its own and this cache belongs to its parent
+        nbt = tuple(b._version for b in ps if b.dtype == torch.int64)
+        key = (precision,) + tuple([(t.data_ptr(), t._version) for t in tensors]) + nbt
         if key != self.key:
             parts = [t.detach().reshape(-1).to(torch.float32) for t in tensors]
             have = sum(p.numel() for p in parts)

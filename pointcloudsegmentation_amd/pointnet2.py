@@ -118,7 +118,10 @@ class _LevelImage:
         for conv, bn in ch:
             tensors += [conv.weight, conv.bias]
             tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [None] * 4
-        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+        # running statistics are also updated through raw pointers (the train-mode kernels), which bumps no version
+        # counter: num_batches_tracked, incremented in place next to every such update, stands in for them
+        nbt = tuple(bn.num_batches_tracked._version for _, bn in ch if bn is not None and bn.num_batches_tracked is not None)
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors) + nbt
         if key != self.key:
             L = _lib.lib()
             dims = [ch[0][0].in_channels] + [c.out_channels for c, _ in ch]
