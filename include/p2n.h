@@ -150,6 +150,14 @@ int p2n_instance_seg_loss(const float *points, const float *emb, const int32_t *
                           float delta_v, float delta_d, int k, float *losses,
                           float *demb_pull, float *demb_push, float *demb_smooth,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the neighbour search (reference losses.py:475-479) done by the caller: knn_idx (B,N,k+1) as written
+ * by p2n_knn_self(points, B, N, k+1).  The search depends on the coordinates only, so a training loop can run it on
+ * a second stream beside the model's forward (reference train.py:124-127 runs model, then criterion). */
+int p2n_instance_seg_loss_knn(const float *points, const float *emb, const int32_t *inst, const int32_t *cnt,
+                              const int32_t *bg, const int32_t *cstart, const int32_t *knn_idx, int B, int N,
+                              int embedding_dim, int T, float delta_v, float delta_d, int k, float *losses,
+                              float *demb_pull, float *demb_push, float *demb_smooth,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /* Label densification for p2n_instance_seg_loss (reference losses.py:389-395: torch.unique per cloud): labels (B,N)
  * int64 -> inst (B*N) dense ids ascending in (cloud,label); cnt / bg (capacity B*max_per_cloud each, the first

@@ -64,6 +64,8 @@ SIGNATURES = {
     "p2n_instance_seg_loss_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "p2n_instance_seg_loss": (c_int, [c_f, c_f, c_i, c_i, c_i, c_i, c_int, c_int, c_int, c_int, c_float, c_float,
                                       c_int, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    "p2n_instance_seg_loss_knn": (c_int, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_int, c_int, c_int, c_int, c_float, c_float,
+                                          c_int, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
     "p2n_sa_group": (c_int, [c_f, c_f, c_f, c_i, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]),
     "p2n_pointwise_layer_workspace_bytes": (c_sz, [c_int, c_int]),
     "p2n_pointwise_layer": (c_int, [c_f, c_int, c_int, ctypes.c_long, c_f, c_f, c_f, c_int, c_int, c_f, c_vp, c_sz, c_vp]),

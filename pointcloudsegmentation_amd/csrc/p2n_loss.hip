@@ -851,11 +851,11 @@ extern "C" size_t p2n_instance_seg_loss_workspace_bytes(int B, int N, int E, int
 // InstanceSegLoss forward (+ gradient).  points (B,N,3), emb (B,N,E); inst (B*N) dense ids,
 // cnt/bg (T), cstart (B+1).  losses[3] = {pull, push, smoothness} (device).  When the three
 // demb_* (B,N,E) are non-NULL they receive d pull / d emb, d push / d emb, d smooth / d emb.
-extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, const int32_t *inst, const int32_t *cnt,
-                                     const int32_t *bg, const int32_t *cstart, int B, int N, int E, int T,
-                                     float delta_v, float delta_d, int k, float *losses, float *demb_pull,
-                                     float *demb_push, float *demb_smooth, void *workspace, size_t workspace_bytes,
-                                     void *stream_) {
+static int loss_run(const float *points, const float *emb, const int32_t *inst, const int32_t *cnt,
+                    const int32_t *bg, const int32_t *cstart, int B, int N, int E, int T,
+                    float delta_v, float delta_d, int k, const int32_t *knn_idx, float *losses, float *demb_pull,
+                    float *demb_push, float *demb_smooth, void *workspace, size_t workspace_bytes,
+                    void *stream_) {
     P2N_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && T >= 1, "p2n_instance_seg_loss: bad shape B=%d N=%d T=%d", B, N, T);
     P2N_REQUIRE(E >= 1 && E <= 256, "p2n_instance_seg_loss: embedding_dim %d not in [1,256]", E);
     P2N_REQUIRE(k >= 1 && k + 1 <= 64, "p2n_instance_seg_loss: k=%d not in [1,63]", k);
@@ -902,12 +902,16 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
                        w.coef);
     P2N_CHECK_HIP(hipGetLastError());
     // smoothness: exact kNN of every point within its own cloud (k+1 incl. the point itself)
-    int rc = p2n_knn_self(points, B, N, k1, w.idx, nullptr, w.knn_ws, w.knn_bytes, stream_);
-    if (rc) return rc;
+    const int *nbr = knn_idx;   // the caller's search result (p2n_instance_seg_loss_knn), or searched here
+    if (!nbr) {
+        int rc = p2n_knn_self(points, B, N, k1, w.idx, nullptr, w.knn_ws, w.knn_bytes, stream_);
+        if (rc) return rc;
+        nbr = w.idx;
+    }
     const float smooth_scale = 1.0f / ((float)N * (float)k) / (float)B;
     const bool fused = P * (long)k1 < 0x7fffffffL;   // reverse-list backward; it also produces the forward partial sums
     if (!want || !fused) {
-        smooth_launch(false, w.en, w.idx, P, N, E, k1, 0.f, w.spart, nullptr, (unsigned)pb, s);
+        smooth_launch(false, w.en, nbr, P, N, E, k1, 0.f, w.spart, nullptr, (unsigned)pb, s);
         P2N_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(p2n_loss_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, w.pull_b, w.push_b, B, w.spart, (long)pb,
                            smooth_scale, losses);
@@ -932,30 +936,53 @@ extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, cons
             if (lds > 48 * 1024)
                 P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_rev_build_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(p2n_rev_build_kernel, dim3(H, B), dim3(REV_THREADS), lds, s, w.idx, B, N, k1, slice, w.off, w.rev);
+            hipLaunchKernelGGL(p2n_rev_build_kernel, dim3(H, B), dim3(REV_THREADS), lds, s, nbr, B, N, k1, slice, w.off, w.rev);
         } else {
         P2N_CHECK_HIP(hipMemsetAsync(w.deg, 0, sizeof(int) * (P + 4), s));
-        hipLaunchKernelGGL(p2n_rev_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, w.idx, P, N, k1, w.deg);
+        hipLaunchKernelGGL(p2n_rev_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, nbr, P, N, k1, w.deg);
         hipLaunchKernelGGL(p2n_scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, s, w.deg, P + 1, w.off, w.totals);
         hipLaunchKernelGGL(p2n_scan_totals_kernel, dim3(1), dim3(256), 0, s, w.totals, nb, w.totals + nb);
         hipLaunchKernelGGL(p2n_scan_add_kernel, dim3((unsigned)nb), dim3(256), 0, s, w.off, P + 1, w.totals);
-        hipLaunchKernelGGL(p2n_rev_fill_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, w.idx, P, N, k1, w.off, w.deg,
+        hipLaunchKernelGGL(p2n_rev_fill_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, nbr, P, N, k1, w.off, w.deg,
                            w.rev);
         }
         const int V = (E + 63) / 64;
-        if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
-        else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
-        else if (V == 3) hipLaunchKernelGGL(p2n_smooth_pull_kernel<3>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
-        else hipLaunchKernelGGL(p2n_smooth_pull_kernel<4>, dim3((unsigned)pb), dim3(256), 0, s, w.en, w.idx, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
+        if (V == 1) hipLaunchKernelGGL(p2n_smooth_pull_kernel<1>, dim3((unsigned)pb), dim3(256), 0, s, w.en, nbr, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
+        else if (V == 2) hipLaunchKernelGGL(p2n_smooth_pull_kernel<2>, dim3((unsigned)pb), dim3(256), 0, s, w.en, nbr, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
+        else if (V == 3) hipLaunchKernelGGL(p2n_smooth_pull_kernel<3>, dim3((unsigned)pb), dim3(256), 0, s, w.en, nbr, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
+        else hipLaunchKernelGGL(p2n_smooth_pull_kernel<4>, dim3((unsigned)pb), dim3(256), 0, s, w.en, nbr, w.off, w.rev, w.rn, P, N, E, k1, smooth_scale, demb_smooth, w.spart);
         hipLaunchKernelGGL(p2n_loss_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, w.pull_b, w.push_b, B, w.spart, (long)pb,
                            smooth_scale, losses);
     } else {
         P2N_CHECK_HIP(hipMemsetAsync(w.den, 0, sizeof(float) * P * E, s));
-        smooth_launch(true, w.en, w.idx, P, N, E, k1, smooth_scale, nullptr, w.den, (unsigned)pb, s);
+        smooth_launch(true, w.en, nbr, P, N, E, k1, smooth_scale, nullptr, w.den, (unsigned)pb, s);
         hipLaunchKernelGGL(p2n_normalize_bwd_kernel, dim3(pb), dim3(256), 0, s, w.den, w.en, w.rn, P, E, demb_smooth);
     }
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
+}
+
+
+extern "C" int p2n_instance_seg_loss(const float *points, const float *emb, const int32_t *inst, const int32_t *cnt,
+                                     const int32_t *bg, const int32_t *cstart, int B, int N, int E, int T,
+                                     float delta_v, float delta_d, int k, float *losses, float *demb_pull,
+                                     float *demb_push, float *demb_smooth, void *workspace, size_t workspace_bytes,
+                                     void *stream_) {
+    return loss_run(points, emb, inst, cnt, bg, cstart, B, N, E, T, delta_v, delta_d, k, nullptr, losses, demb_pull,
+                    demb_push, demb_smooth, workspace, workspace_bytes, stream_);
+}
+
+// The same with the neighbour search done by the caller: knn_idx (B,N,k+1) = p2n_knn_self(points, k+1).  The search
+// depends on the coordinates only, so a training loop can run it on a second stream beside the model's forward
+// (pointcloudsegmentation_amd/losses.py: InstanceSegLoss.prepare) instead of between the forward and the backward.
+extern "C" int p2n_instance_seg_loss_knn(const float *points, const float *emb, const int32_t *inst, const int32_t *cnt,
+                                         const int32_t *bg, const int32_t *cstart, const int32_t *knn_idx, int B, int N,
+                                         int E, int T, float delta_v, float delta_d, int k, float *losses,
+                                         float *demb_pull, float *demb_push, float *demb_smooth, void *workspace,
+                                         size_t workspace_bytes, void *stream_) {
+    P2N_REQUIRE(knn_idx, "p2n_instance_seg_loss_knn: null knn_idx");
+    return loss_run(points, emb, inst, cnt, bg, cstart, B, N, E, T, delta_v, delta_d, k, knn_idx, losses, demb_pull,
+                    demb_push, demb_smooth, workspace, workspace_bytes, stream_);
 }
 
 // =========================================================================== label densification

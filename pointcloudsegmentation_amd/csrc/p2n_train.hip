@@ -305,71 +305,89 @@ struct WgStage {
     f32x4 v0[4], v1[4];
 };
 
+// Every load is unconditional (see tl_fetch: a conditional load ends in a select behind an s_waitcnt right where the
+// load was issued, and the "prefetch" of the next block was waited for in front of the MFMAs it was meant to hide
+// behind).  Rows past the operand's extent read its last row, points past the slice read on inside the padded row
+// (channel-major rows have Ppad columns, and a 64-point step never crosses Ppad) or the last point (point-major);
+// wgrad_park writes zeros for all of those.
 template <int MODE>
 __device__ __forceinline__ void wgrad_fetch(WgStage<MODE> &st, const float *__restrict__ s0, const float *__restrict__ s1,
                                             int row0, int nrows, long p0, long pend, int Ppad, int ld) {
     const int t = threadIdx.x;
     if (MODE == LD_BNBWD || MODE == LD_BNRELU || MODE == LD_PLAIN) {
         const int seg = (t & 3) * 16;
-        const int row = row0 + (t >> 2);
+        int row = row0 + (t >> 2);
+        row = row < nrows ? row : nrows - 1;
+        const float *q0 = s0 + (long)row * Ppad + p0 + seg;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long p = p0 + seg + 4 * i;
-            st.v0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            st.v1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < nrows && p < pend) {   // slices start at multiples of 64 and Ppad is a multiple of 128: in-row loads
-                st.v0[i] = *reinterpret_cast<const f32x4 *>(s0 + (long)row * Ppad + p);
-                if (MODE == LD_BNBWD) st.v1[i] = *reinterpret_cast<const f32x4 *>(s1 + (long)row * Ppad + p);
-            }
+        for (int i = 0; i < 4; ++i) st.v0[i] = *reinterpret_cast<const f32x4 *>(q0 + 4 * i);
+        if (MODE == LD_BNBWD) {
+            const float *q1 = s1 + (long)row * Ppad + p0 + seg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st.v1[i] = *reinterpret_cast<const f32x4 *>(q1 + 4 * i);
         }
     } else {   // point-major sources: gemb (P,E) or x (P,F)
         const int seg = (t >> 6) * 16;
-        const int row = row0 + (t & 63);
+        int row = row0 + (t & 63);
+        row = row < nrows ? row : nrows - 1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const long p = p0 + seg + i;
-            st.v0[i >> 2][i & 3] = (row < nrows && p < pend) ? s0[p * ld + row] : 0.f;
+            long p = p0 + seg + i;
+            p = p < pend ? p : pend - 1;
+            st.v0[i >> 2][i & 3] = s0[p * ld + row];
         }
     }
 }
 
+// The per-row constants of the fused transform: the row a thread parks never changes, so they are read once, ahead of
+// the loop (a load inside the loop, even an already-consumed one, makes the compiler drain the prefetch of the next
+// block in front of the MFMAs whenever its register is reused).
+struct WgConst { float c0, c1, c2, c3, c4; };
+
 template <int MODE>
-__device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__restrict__ dst, const float *__restrict__ tab,
-                                           int row0, int nrows, int ntab, long p0, long pend) {
+__device__ __forceinline__ WgConst wgrad_const(const float *__restrict__ tab, int row0, int nrows, int ntab) {
+    WgConst c = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MODE == LD_BNBWD || MODE == LD_BNRELU) {
+        int row = row0 + (int)(threadIdx.x >> 2);
+        row = row < nrows ? row : nrows - 1;
+        c.c0 = tab[row]; c.c1 = tab[ntab + row];
+        if (MODE == LD_BNBWD) { c.c2 = tab[2 * ntab + row]; c.c3 = tab[3 * ntab + row]; c.c4 = tab[4 * ntab + row]; }
+    }
+    return c;
+}
+
+template <int MODE>
+__device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__restrict__ dst, const WgConst &c,
+                                           int row0, int nrows, long p0, long pend) {
     const int t = threadIdx.x;
     if (MODE == LD_BNBWD || MODE == LD_BNRELU || MODE == LD_PLAIN) {
         const int r = t >> 2, seg = (t & 3) * 16;
-        const int row = row0 + r;
-        const bool rok = row < nrows;
-        float c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-        if (rok && MODE != LD_PLAIN) {
-            c0 = tab[row]; c1 = tab[ntab + row];
-            if (MODE == LD_BNBWD) { c2 = tab[2 * ntab + row]; c3 = tab[3 * ntab + row]; c4 = tab[4 * ntab + row]; }
-        }
+        const bool rok = row0 + r < nrows;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long p = p0 + seg + 4 * i;
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            if (rok && p < pend) {
+            f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (MODE == LD_BNBWD) {
-                        const float z = st.v1[i][j];
-                        const float dy = fmaf(z, c0, c1) > 0.f ? st.v0[i][j] : 0.f;
-                        o[j] = (p + j < pend) ? fmaf(c4, z, fmaf(c2, dy, c3)) : 0.f;
-                    } else if (MODE == LD_PLAIN) {
-                        o[j] = (p + j < pend) ? st.v0[i][j] : 0.f;
-                    } else {
-                        o[j] = (p + j < pend) ? fmaxf(fmaf(st.v0[i][j], c0, c1), 0.f) : 0.f;
-                    }
+            for (int j = 0; j < 4; ++j) {
+                float v;
+                if (MODE == LD_BNBWD) {
+                    const float z = st.v1[i][j];
+                    const float dy = fmaf(z, c.c0, c.c1) > 0.f ? st.v0[i][j] : 0.f;
+                    v = fmaf(c.c4, z, fmaf(c.c2, dy, c.c3));
+                } else if (MODE == LD_PLAIN) {
+                    v = st.v0[i][j];
+                } else {
+                    v = fmaxf(fmaf(st.v0[i][j], c.c0, c.c1), 0.f);
                 }
+                o[j] = (rok && p + j < pend) ? v : 0.f;
             }
             *reinterpret_cast<f32x4 *>(dst + r * WG_LD + seg + 4 * i) = o;
         }
     } else {
         const int r = t & 63, seg = (t >> 6) * 16;
+        const bool rok = row0 + r < nrows;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[r * WG_LD + seg + i] = st.v0[i >> 2][i & 3];
+        for (int i = 0; i < 16; ++i) dst[r * WG_LD + seg + i] = (rok && p0 + seg + i < pend) ? st.v0[i >> 2][i & 3] : 0.f;
     }
 }
 
@@ -402,13 +420,18 @@ __global__ __launch_bounds__(256, 2) void p2n_wgrad_kernel(WgArgs A) {   // two 
 #pragma unroll
         for (int k = 0; k < CT; ++k) wgrad_fetch<BMODE>(stb[k], A.b0, nullptr, (bc * CT + k) * WG_TILE, A.cols, p0, s1, A.Ppad, A.ld_b);
     };
+    WgConst ca[RT], cb[CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) ca[i] = wgrad_const<AMODE>(A.atab, (br * RT + i) * WG_TILE, A.rows, A.rows);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) cb[k] = wgrad_const<BMODE>(A.btab, (bc * CT + k) * WG_TILE, A.cols, A.cols);
     auto park = [&](long p0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
-            wgrad_park<AMODE>(sta[i], sa + i * WG_TILE * WG_LD, A.atab, (br * RT + i) * WG_TILE, A.rows, A.rows, p0, s1);
+            wgrad_park<AMODE>(sta[i], sa + i * WG_TILE * WG_LD, ca[i], (br * RT + i) * WG_TILE, A.rows, p0, s1);
 #pragma unroll
         for (int k = 0; k < CT; ++k)
-            wgrad_park<BMODE>(stb[k], sb + k * WG_TILE * WG_LD, A.btab, (bc * CT + k) * WG_TILE, A.cols, A.cols, p0, s1);
+            wgrad_park<BMODE>(stb[k], sb + k * WG_TILE * WG_LD, cb[k], (bc * CT + k) * WG_TILE, A.cols, p0, s1);
     };
     if (s0 < s1) {
         fetch(s0);

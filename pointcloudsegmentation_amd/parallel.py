@@ -89,6 +89,8 @@ def train_step(model, criterion, optimizer, features, labels, max_norm: float = 
     backward, (all-reduce), clip_grad_norm_(1.0), optimizer.step().  Returns the loss dict."""
     points = features[:, :, :3].contiguous()
     optimizer.zero_grad()
+    if hasattr(criterion, "prepare"):
+        criterion.prepare(points, labels)      # neighbour search + label ids on a second stream, beside the forward
     emb = model(features)
     out = criterion(points, emb, labels)
     out["total_loss"].backward()

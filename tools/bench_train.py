@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--global-batch", type=int, default=32)
     ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--no-prepare", action="store_true", help="do not start the loss's neighbour search beside the forward")
     ap.add_argument("--no-loss", action="store_true", help="loss = emb.sum() (model fwd+bwd only)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -53,6 +54,8 @@ def main():
 
     def step():
         opt.zero_grad()
+        if not args.no_loss and not args.no_prepare:
+            crit.prepare(pts, y)
         emb = model(x)
         loss = emb.sum() if args.no_loss else crit(pts, emb, y)["total_loss"]
         loss.backward()
