@@ -1285,18 +1285,91 @@ extern "C" int p2n_group_gather(const float *feat, const int32_t *idx, int B, in
     return P2N_OK;
 }
 
+// Adjoints of the two gathers with the accumulation in LDS.  The first versions (kept below for rows that do not fit)
+// sent one fp32 atomic per (channel, source element) to L2: 50-70 M atomics per call at the set-abstraction shapes,
+// 0.6 / 1.0 ms.  Here a workgroup owns CH whole rows of the result -- (cloud b, channels c0..c0+CH) -- keeps them in
+// LDS, streams the sources past them (index and gradient reads coalesced, ds_add_f32 on LDS banks) and writes the
+// rows out once with plain stores: no global atomic, no zero fill.  With few (b, channel) pairs the source range is
+// cut into S slices whose workgroups add their rows with global atomics (gfeat zeroed first).  Summation order
+// inside a row is still that of the LDS atomics (not reproducible run to run, like the first versions).
+#define ADJ_MAX_LDS (128 * 1024)
+
+template <int CH>
+__global__ __launch_bounds__(512) void p2n_group_gather_bwd_lds_kernel(const float *__restrict__ gout,
+                                                                      const int32_t *__restrict__ idx, int C, int N,
+                                                                      long MS, long slice, int S,
+                                                                      float *__restrict__ gfeat) {
+    extern __shared__ float acc[];   // [CH][N]
+    const int b = blockIdx.z, c0 = blockIdx.y * CH;
+    for (int i = threadIdx.x; i < CH * N; i += 512) acc[i] = 0.f;
+    __syncthreads();
+    const long j0 = (long)blockIdx.x * slice;
+    long j1 = j0 + slice;
+    if (j1 > MS) j1 = MS;
+    const int32_t *ib = idx + (long)b * MS;
+    for (long j = j0 + threadIdx.x; j < j1; j += 512) {
+        const int i = clamp_idx(ib[j], N);
+        float g[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) g[c] = c0 + c < C ? gout[((long)b * C + c0 + c) * MS + j] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) atomicAdd(&acc[c * N + i], g[c]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CH * N; i += 512) {
+        const int c = i / N, k = i - c * N;
+        if (c0 + c >= C) break;
+        float *dst = &gfeat[((long)b * C + c0 + c) * N + k];
+        if (S == 1) *dst = acc[i];
+        else if (acc[i] != 0.f) atomicAdd(dst, acc[i]);
+    }
+}
+
+// channels per workgroup for rows of `len` floats (0: a row does not fit the LDS budget), slices for `pairs` (b, block) pairs
+static int adj_channels(long len) {
+    for (int ch = 8; ch >= 1; ch >>= 1)
+        if ((long)ch * len * (long)sizeof(float) <= ADJ_MAX_LDS) return ch;
+    return 0;
+}
+
+static int adj_slices(long pairs, long sources) {
+    int S = 1;
+    while (pairs * S < 256 && sources / (S * 2) >= 4096 && S < 64) S *= 2;
+    return S;
+}
+
 extern "C" int p2n_group_gather_bwd(const float *gout, const int32_t *idx, int B, int C, int N, int M, int ns,
                                     float *gfeat, void *stream) {
     P2N_REQUIRE(B >= 0 && C >= 0 && N >= 1 && M >= 0 && ns >= 0, "p2n_group_gather_bwd: bad shape");
     const long MS = (long)M * ns;
     if (B == 0 || C == 0) return P2N_OK;
     P2N_REQUIRE(gfeat, "p2n_group_gather_bwd: null pointer");
-    P2N_CHECK_HIP(hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * N, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = adj_channels(N);
+    const long nblk = ch ? (C + ch - 1) / ch : 0;
+    const int S = ch ? adj_slices((long)B * nblk, MS) : 0;
+    if (!ch || S > 1 || MS == 0) P2N_CHECK_HIP(hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * N, s));
     if (MS == 0) return P2N_OK;
     P2N_REQUIRE(gout && idx, "p2n_group_gather_bwd: null pointer");
-    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_group_gather_bwd: B or C too large");
-    hipLaunchKernelGGL(p2n_group_gather_bwd_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
-                       dim3(256), 0, (hipStream_t)stream, gout, idx, C, N, MS, gfeat);
+    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535 && C <= 65535, "p2n_group_gather_bwd: B or C too large");
+    if (ch) {
+        const long slice = ((MS + S - 1) / S + 511) / 512 * 512;
+        const size_t lds = sizeof(float) * (size_t)ch * N;
+        const dim3 grid((unsigned)((MS + slice - 1) / slice), (unsigned)nblk, B);
+#define ADJ_GO(CHV)                                                                                                     \
+    do {                                                                                                                \
+        if (lds > 48 * 1024)                                                                                            \
+            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_group_gather_bwd_lds_kernel<CHV>),    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL(p2n_group_gather_bwd_lds_kernel<CHV>, grid, dim3(512), lds, s, gout, idx, C, N, MS, slice,    \
+                           (int)grid.x, gfeat);                                                                         \
+    } while (0)
+        if (ch == 8) ADJ_GO(8); else if (ch == 4) ADJ_GO(4); else if (ch == 2) ADJ_GO(2); else ADJ_GO(1);
+#undef ADJ_GO
+    } else {
+        hipLaunchKernelGGL(p2n_group_gather_bwd_kernel, dim3((unsigned)((MS + 255) / 256), (C + GG_CH - 1) / GG_CH, B),
+                           dim3(256), 0, s, gout, idx, C, N, MS, gfeat);
+    }
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
@@ -1503,17 +1576,73 @@ extern "C" int p2n_three_interpolate(const float *feat, const int32_t *idx, cons
     return P2N_OK;
 }
 
+template <int CH>
+__global__ __launch_bounds__(512) void p2n_three_interp_bwd_lds_kernel(const float *__restrict__ gout,
+                                                                      const int32_t *__restrict__ idx,
+                                                                      const float *__restrict__ w, int C, int m, int n,
+                                                                      int slice, int S, float *__restrict__ gfeat) {
+    extern __shared__ float acc[];   // [CH][m]
+    const int b = blockIdx.z, c0 = blockIdx.y * CH;
+    for (int i = threadIdx.x; i < CH * m; i += 512) acc[i] = 0.f;
+    __syncthreads();
+    const int p0 = blockIdx.x * slice;
+    const int p1 = p0 + slice < n ? p0 + slice : n;
+    for (int i = p0 + threadIdx.x; i < p1; i += 512) {
+        const int32_t *id = idx + ((long)b * n + i) * 3;
+        const float *ww = w + ((long)b * n + i) * 3;
+        const int i0 = clamp_idx(id[0], m), i1 = clamp_idx(id[1], m), i2 = clamp_idx(id[2], m);
+        const float w0 = ww[0], w1 = ww[1], w2 = ww[2];
+        float g[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) g[c] = c0 + c < C ? gout[((long)b * C + c0 + c) * n + i] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            atomicAdd(&acc[c * m + i0], g[c] * w0);
+            atomicAdd(&acc[c * m + i1], g[c] * w1);
+            atomicAdd(&acc[c * m + i2], g[c] * w2);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CH * m; i += 512) {
+        const int c = i / m, k = i - c * m;
+        if (c0 + c >= C) break;
+        float *dst = &gfeat[((long)b * C + c0 + c) * m + k];
+        if (S == 1) *dst = acc[i];
+        else if (acc[i] != 0.f) atomicAdd(dst, acc[i]);
+    }
+}
+
 extern "C" int p2n_three_interpolate_bwd(const float *gout, const int32_t *idx, const float *weight, int B, int C,
                                          int m, int n, float *gfeat, void *stream) {
     P2N_REQUIRE(B >= 0 && C >= 0 && m >= 1 && n >= 0, "p2n_three_interpolate_bwd: bad shape");
     if (B == 0 || C == 0) return P2N_OK;
     P2N_REQUIRE(gfeat, "p2n_three_interpolate_bwd: null pointer");
-    P2N_CHECK_HIP(hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * m, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = adj_channels(m);
+    const long nblk = ch ? (C + ch - 1) / ch : 0;
+    const int S = ch ? adj_slices((long)B * nblk, n) : 0;
+    if (!ch || S > 1 || n == 0) P2N_CHECK_HIP(hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * m, s));
     if (n == 0) return P2N_OK;
     P2N_REQUIRE(gout && idx && weight, "p2n_three_interpolate_bwd: null pointer");
-    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535, "p2n_three_interpolate_bwd: B or C too large");
-    hipLaunchKernelGGL(p2n_three_interp_bwd_kernel, dim3((n + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
-                       (hipStream_t)stream, gout, idx, weight, C, m, n, gfeat);
+    P2N_REQUIRE(B <= 65535 && (C + GG_CH - 1) / GG_CH <= 65535 && C <= 65535, "p2n_three_interpolate_bwd: B or C too large");
+    if (ch) {
+        const int slice = ((n + S - 1) / S + 511) / 512 * 512;
+        const size_t lds = sizeof(float) * (size_t)ch * m;
+        const dim3 grid((unsigned)((n + slice - 1) / slice), (unsigned)nblk, B);
+#define ADJ_GO(CHV)                                                                                                     \
+    do {                                                                                                                \
+        if (lds > 48 * 1024)                                                                                            \
+            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_three_interp_bwd_lds_kernel<CHV>),    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL(p2n_three_interp_bwd_lds_kernel<CHV>, grid, dim3(512), lds, s, gout, idx, weight, C, m, n,    \
+                           slice, (int)grid.x, gfeat);                                                                  \
+    } while (0)
+        if (ch == 8) ADJ_GO(8); else if (ch == 4) ADJ_GO(4); else if (ch == 2) ADJ_GO(2); else ADJ_GO(1);
+#undef ADJ_GO
+    } else {
+        hipLaunchKernelGGL(p2n_three_interp_bwd_kernel, dim3((n + 255) / 256, (C + GG_CH - 1) / GG_CH, B), dim3(256), 0,
+                           s, gout, idx, weight, C, m, n, gfeat);
+    }
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }

@@ -313,6 +313,58 @@ def test_three_interpolate_fwd_bwd():
     np.testing.assert_allclose(ft.grad.cpu().numpy(), g, rtol=1e-4, atol=1e-5)
 
 
+# Adjoints: LDS-accumulating kernels (8 / 4 / 2 / 1 channel rows per workgroup by row length, source range cut
+# into slices when there are few (cloud, channel block) pairs) and the global-atomic kernels for rows beyond LDS.
+@pytest.mark.parametrize("B,C,N,M,ns", [
+    (2, 19, 500, 40, 16),       # 8 rows per workgroup, channel tail
+    (16, 64, 8192, 512, 32),    # set-abstraction level 1 shape (M reduced): 4 rows per workgroup
+    (1, 3, 8192, 2048, 32),     # one channel block: 64 slices, atomic flush
+    (1, 2, 20000, 300, 8),      # one row per workgroup
+    (1, 2, 40000, 300, 8),      # row beyond the LDS budget: global-atomic kernel
+])
+def test_group_gather_bwd_variants(B, C, N, M, ns):
+    from pointcloudsegmentation_amd import ops
+    rng = np.random.default_rng(N + C)
+    idx = rng.integers(0, N, size=(B, M, ns)).astype(np.int32)
+    idx[:, :, 0] = idx[:, :1, 0]           # many sources on one target
+    ft = torch.zeros(B, C, N, device="cuda", requires_grad=True)
+    out = ops.group_gather(ft, torch.from_numpy(idx).cuda())
+    w = torch.from_numpy(rng.standard_normal((B, C, M, ns)).astype(np.float32)).cuda()
+    (out * w).sum().backward()
+    it = torch.from_numpy(idx.reshape(B, 1, -1).astype(np.int64)).cuda().expand(B, C, M * ns)
+    want = torch.zeros(B, C, N, dtype=torch.float64, device="cuda").scatter_add_(2, it, w.double().reshape(B, C, -1))
+    scale = float(want.abs().max())
+    assert float((ft.grad.double() - want).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("B,C,m,n", [
+    (2, 21, 128, 700),
+    (16, 128, 2048, 8192),      # feature-propagation level 1 shape
+    (16, 256, 128, 512),        # coarsest level
+    (1, 5, 512, 40000),         # one channel block: slices, atomic flush
+    (1, 2, 40000, 50000),       # row beyond the LDS budget: global-atomic kernel
+])
+def test_three_interpolate_bwd_variants(B, C, m, n):
+    from pointcloudsegmentation_amd import ops
+    rng = np.random.default_rng(m + n)
+    idx = rng.integers(0, m, size=(B, n, 3)).astype(np.int32)
+    idx[:, ::7, 1] = idx[:, ::7, 0]        # a coarse point twice in one triple
+    wt = rng.random((B, n, 3)).astype(np.float32)
+    wt /= wt.sum(-1, keepdims=True)
+    ft = torch.zeros(B, C, m, device="cuda", requires_grad=True)
+    out = ops.three_interpolate(ft, torch.from_numpy(idx).cuda(), torch.from_numpy(wt).cuda())
+    go = torch.from_numpy(rng.standard_normal((B, C, n)).astype(np.float32)).cuda()
+    (out * go).sum().backward()
+    want = torch.zeros(B, C, m, dtype=torch.float64, device="cuda")
+    it = torch.from_numpy(idx.astype(np.int64)).cuda()
+    wd = torch.from_numpy(wt).cuda()
+    for j in range(3):
+        contrib = (go * wd[:, None, :, j]).double()          # the kernel forms g*w in float32 as well
+        want.scatter_add_(2, it[:, None, :, j].expand(B, C, n), contrib)
+    scale = float(want.abs().max())
+    assert float((ft.grad.double() - want).abs().max()) <= 2e-6 * scale
+
+
 # LDS-staged and global-gather variants of the same operators: shapes on both sides of the
 # launcher's conditions (row length / column count multiples of four, rows that fit LDS or not,
 # channel tails, several column splits) must give identical bits.
