@@ -11,13 +11,13 @@
 
 // Tuning overrides for the sweep tools (tools/fps_sweep.py, tools/sweep_gather.sh), read from the
 // environment once per process: 0 / unset = the built-in choice.
-struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd; };
+struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd, fps_prune, fps_pw; };
 static const P2nTuning &p2n_tuning() {
     static const P2nTuning t = [] {
         auto num = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
         return P2nTuning{num("P2N_FPS_G"), num("P2N_GL_CH"), num("P2N_GL_THREADS"), num("P2N_GL_SPLIT"),
                          getenv("P2N_GL_OFF") ? 1 : 0, num("P2N_FPS_T"), num("P2N_FPS_SPIN"),
-                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD")};
+                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD"), num("P2N_FPS_PRUNE"), num("P2N_FPS_PW")};
     }();
     return t;
 }
@@ -305,6 +305,10 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
     }
 }
 
+// bucket-pruned single-workgroup variant (defined behind the Morton sort it builds on)
+static size_t fps_pruned_bytes(int B, int N, int M);
+static int fps_pruned_run(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, void *scratch, hipStream_t s);
+
 // Launch plan: workgroups per cloud, threads, points per thread.
 struct FpsPlan { int G, T, ppt; };
 static const int kFpsPpt256[] = {2, 4, 8, 16, 24, 32, 40, 48};
@@ -379,7 +383,7 @@ extern "C" size_t p2n_fps_workspace_bytes(int B, int N, int M) {
     // slots of the largest sub-batch: at most 64 workgroups per cloud, 32 bytes each per sample
     const FpsPlan p = fps_plan(1, N);
     const int gmax = p.G > 1 ? 64 : 1;
-    return 16 + (gmax > 1 ? sizeof(u64) * 4 * (size_t)B * (M + 1) * gmax : 0);
+    return 256 + (gmax > 1 ? sizeof(u64) * 4 * (size_t)B * (M + 1) * gmax : 0) + fps_pruned_bytes(B, N, M);
 }
 
 template <int T, int PPT, bool LDSXYZ>
@@ -415,9 +419,14 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         p2n_set_error("p2n_fps: workspace %zu bytes < required %zu", workspace_bytes, need);
         return P2N_EWORKSPACE;
     }
+    if (!status) P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));   // no private status word: the workspace's
+    if (fps_pruned_bytes(B, N, M)) {   // one workgroup per cloud, no exchange: nothing can time out, the status stays as it is
+        const FpsPlan p1 = fps_plan(1, N);
+        const size_t off = 256 + (p1.G > 1 ? sizeof(u64) * 4 * (size_t)B * (M + 1) * 64 : 0);
+        return fps_pruned_run(xyz, B, N, M, start_idx, idx, (char *)workspace + off, stream);
+    }
     // sub-batches so that every launch's workgroups are co-resident (<= 256)
     int done = 0;
-    if (!status) P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));   // no private status word: the workspace's
     const int ncu = fps_cus();
     const int spin = p2n_tuning().fps_spin > 0 ? p2n_tuning().fps_spin : FPS_SPIN_LIMIT;
     while (done < B) {
@@ -434,10 +443,10 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         a.nb = nb;
         // one XCD per cloud when its cluster and the other clouds sharing that XCD fit the XCD's 32 CUs
         a.xcd_mode = p.G > 1 && p.G * ((nb + 7) / 8) <= ncu / 8 && !p2n_tuning().fps_noxcd;
-        a.slots = (u64 *)((char *)workspace + 16);
+        a.slots = (u64 *)((char *)workspace + 256);
         a.N = N; a.M = M; a.G = p.G; a.chunk = (N + p.G - 1) / p.G; a.start_idx = start_idx; a.b0 = done;
         if (p.G > 1)   // launches run in stream order, so they can share the slot region
-            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 16, 0, sizeof(u64) * 4 * (size_t)nb * (M + 1) * p.G, stream));
+            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 256, 0, sizeof(u64) * 4 * (size_t)nb * (M + 1) * p.G, stream));
         hipError_t e = hipErrorInvalidValue;
         if (p.T == 256) {
             switch (p.ppt) {
@@ -807,6 +816,187 @@ __global__ __launch_bounds__(KS_THREADS) void p2n_knn_sort_kernel(const float *_
             boxes[((long)b * ntiles + tile) * 2 + 1] = float4{hi[0], hi[1], hi[2], 0.f};
         }
     }
+}
+
+// =========================================================================== FPS, bucket-pruned
+// Farthest point sampling of a cloud that one workgroup holds, with the work of an iteration cut to the buckets
+// the new sample can change.  A point's running minimum changes only if the new sample is closer than that
+// minimum, so a 64-point bucket whose bounding box is at least as far from the sample as the bucket's LARGEST
+// running minimum keeps every minimum, hence its cached (maximum, lowest index) key.  On Morton-ordered points
+// (p2n_knn_sort_kernel: ordered copy + one box per 64-point tile) a sample reaches ~10 of the 128 buckets of an
+// 8,192-point cloud (~36 in the first 64 iterations), so the iteration is the reduction chain plus a few buckets
+// instead of 32 points per thread (0.80 -> 0.58 us per sample at 8,192 points, 1.07 -> see DESIGN at 12,288).
+// Layout: wave w owns buckets w, w+W, w+2W, ...; slot s of lane j is point j of bucket s*W+w (registers, as in the
+// dense kernel); lane s of the wave keeps the box and the key of the wave's slot s.  Per iteration: every lane tests its bucket's box
+// (same ((ex*ex + ey*ey) + ez*ez) roundings as a point's distance and IEEE rounding is monotonic, so the bound never
+// exceeds the computed distance of a point inside the box; a bucket is skipped only if bound >= its maximum, where no
+// minimum can change), the wave walks the set bits of the ballot and, per active bucket, updates its 64 minima,
+// takes their maximum by DPP and the lowest original index attaining it, and writes the key into lane s.
+// Results are those of the dense kernel bit for bit: the same distances, and ties go to the lowest ORIGINAL index
+// (the keys carry it; the order of the copy steers speed only).
+struct FpsPrArgs {
+    const float *xyz;      // (B,N,3)
+    const float4 *sorted;  // [B][ntiles*64] (x,y,z,original index; -1 = pad)
+    const float4 *boxes;   // [B][ntiles][2]
+    int32_t *idx;          // (B,M)
+    int N, M, ntiles, start_idx;
+};
+
+template <int W, int S>
+__global__ __launch_bounds__(W * 64) void p2n_fps_pruned_kernel(FpsPrArgs A) {
+    static_assert(S >= 4 && S <= 32 && S % 4 == 0, "bucket keys live in lanes 0..S-1, slots are walked in groups of four");
+    extern __shared__ __attribute__((aligned(16))) float lxyz[];   // the cloud by ORIGINAL index, [point][3]: the winner's coordinates
+    __shared__ u64 wkey[3];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x;
+    const float *P = A.xyz + (long)b * A.N * 3;
+    for (int i = t; i < A.N * 3; i += W * 64) lxyz[i] = P[i];
+    if (t < 3) wkey[t] = 0ull;
+    const float INF = __int_as_float(0x7f800000);
+    const float4 *Sd = A.sorted + (long)b * A.ntiles * 64;
+    float px[S], py[S], pz[S], md[S];
+    unsigned pv[S];   // 0xFFFFFFFF - original index (0 for pads): maxima everywhere
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int tile = s * W + wave;   // neighbouring buckets go to different waves: a sample's few active buckets are neighbours
+        float4 p = {0.f, 0.f, 0.f, __int_as_float(-1)};
+        if (tile < A.ntiles) p = Sd[(long)tile * 64 + lane];
+        const bool valid = __float_as_int(p.w) >= 0;
+        px[s] = p.x; py[s] = p.y; pz[s] = p.z;
+        md[s] = valid ? INF : 0.f;   // pads: minimum 0 and the lowest key, they lose every tie
+        pv[s] = valid ? 0xFFFFFFFFu - (unsigned)__float_as_int(p.w) : 0u;
+    }
+    float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};   // the box of bucket `lane` of this wave
+    {
+        const int tile = lane * W + wave;
+        if (lane < S && tile < A.ntiles) {
+            const float4 l4 = A.boxes[((long)b * A.ntiles + tile) * 2], h4 = A.boxes[((long)b * A.ntiles + tile) * 2 + 1];
+            lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z; hi[0] = h4.x; hi[1] = h4.y; hi[2] = h4.z;
+        }
+    }
+    unsigned bkd = 0u, bkv = 0u;   // lane s: bits of bucket s's largest running minimum, and its 0xFFFFFFFF - index
+    __syncthreads();
+    int cur = A.start_idx;
+    float cx = lxyz[cur * 3 + 0], cy = lxyz[cur * 3 + 1], cz = lxyz[cur * 3 + 2];
+    int kb = 0;
+    for (int it = 0; it < A.M; ++it) {
+        if (t == 0) A.idx[(long)b * A.M + it] = cur;
+        if (it + 1 == A.M) break;
+        // ---- which buckets can the new sample change?
+        const float ex = fmaxf(fmaxf(__fsub_rn(lo[0], cx), __fsub_rn(cx, hi[0])), 0.f);
+        const float ey = fmaxf(fmaxf(__fsub_rn(lo[1], cy), __fsub_rn(cy, hi[1])), 0.f);
+        const float ez = fmaxf(fmaxf(__fsub_rn(lo[2], cz), __fsub_rn(cz, hi[2])), 0.f);
+        const float bound = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+        u64 m = __ballot(bound < __uint_as_float(bkd));
+        if (it == 0) m = (1ull << S) - 1;   // the first sample sets every minimum (and every bucket key)
+        m &= (1ull << S) - 1;
+        const unsigned mlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m);
+        // wave-uniform walk over the active buckets: groups of four slots, then single slots (scalar tests; a `switch`
+        // on the slot number made the compiler compute every slot's distance ahead of the branch and copy the
+        // minima around).  The sample's coordinates pass through an opaque move inside the block, so that nothing
+        // of a slot's work can be hoisted out of its branch.
+#pragma unroll
+        for (int g4 = 0; g4 < S / 4; ++g4) {
+            if ((mlo >> (4 * g4)) & 0xFu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sl = 4 * g4 + j;
+                    if ((mlo >> sl) & 1u) {
+                        float qx = cx, qy = cy, qz = cz;
+                        asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+                        const float d = sqdist3(px[sl], py[sl], pz[sl], qx, qy, qz);
+                        float mnew;
+                        asm("v_min_f32 %0, %1, %2" : "=v"(mnew) : "v"(md[sl]), "v"(d));
+                        md[sl] = mnew;
+                        const unsigned bits = __float_as_uint(mnew);
+                        const unsigned mx = wave_max_u32(bits);
+                        const u64 eq = __ballot(bits == mx);
+                        unsigned bv;
+                        if (__builtin_popcountll(eq) == 1) bv = (unsigned)__builtin_amdgcn_readlane((int)pv[sl], __builtin_ctzll(eq));
+                        else bv = wave_max_u32(bits == mx ? pv[sl] : 0u);
+                        bkd = lane == sl ? mx : bkd;   // mx, bv are wave-uniform
+                        bkv = lane == sl ? bv : bkv;
+                    }
+                }
+            }
+        }
+        // ---- workgroup argmax over the bucket keys (lanes >= S hold the zero key), as in the dense kernel
+        const unsigned rhi = row16_max_u32(bkd);
+        const unsigned rlo = row16_max_u32(bkd == rhi ? bkv : 0u);
+        if ((lane & 15) == 0) lds_max_u64(&wkey[kb], ((u64)rhi << 32) | rlo);
+        __syncthreads();
+        const u64 k = wkey[kb];
+        const int kclr = kb == 0 ? 2 : kb - 1;
+        if (t == 0) wkey[kclr] = 0ull;
+        kb = kb == 2 ? 0 : kb + 1;
+        cur = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));
+        cx = lxyz[cur * 3 + 0]; cy = lxyz[cur * 3 + 1]; cz = lxyz[cur * 3 + 2];
+    }
+}
+
+// Waves per workgroup x slots per wave.  Sixteen thin waves: what an iteration costs beyond the reduction chain is the
+// SERIAL walk of a wave over its active buckets (~250 dependent cycles each: distance, minimum, DPP maximum, ballot,
+// lane read), and neighbouring buckets sit in different waves, so more waves = fewer active buckets per wave
+// (8,192 points: 0.93 us per sample with 4 waves, 0.72 with 8, 0.58 with 16; dense kernel 0.80).
+static void fps_pruned_shape(int N, int *W, int *S) {
+    const int ntiles = (N + 63) / 64;
+    const int pw = p2n_tuning().fps_pw;   // P2N_FPS_PW: waves per workgroup (4 / 8), sweeps only
+    if (pw == 4 && ntiles <= 128) { *W = 4; *S = ntiles <= 32 ? 8 : ntiles <= 64 ? 16 : ntiles <= 96 ? 24 : 32; return; }
+    if (pw == 8) { *W = 8; *S = ntiles <= 64 ? 8 : ntiles <= 128 ? 16 : 24; return; }
+    *W = 16;
+    *S = ntiles <= 128 ? 8 : 12;
+}
+
+// scratch bytes of the pruned path, 0 = this shape takes the dense kernels
+static size_t fps_pruned_bytes(int B, int N, int M) {
+    const int mode = p2n_tuning().fps_prune;   // P2N_FPS_PRUNE: 1 = never, 2 = whenever the shape allows
+    if (mode == 1 || B < 1 || N > FPS_LDS_POINTS || N > KS_MAX_N) return 0;
+    if (mode != 2 && (N < 5120 || M < 64)) return 0;   // smaller clouds: the dense kernel's iteration (0.42-0.6 us) is at the chain's floor already
+    const size_t ntiles = ((size_t)N + 63) / 64;
+    return (((size_t)B * ntiles * 64 * sizeof(float4) + 255) & ~(size_t)255) + (size_t)B * ntiles * 2 * sizeof(float4) + 256;
+}
+
+template <int W, int S>
+static hipError_t fps_pruned_launch(const FpsPrArgs &a, int B, hipStream_t s) {
+    const size_t lds = (size_t)a.N * 12;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_fps_pruned_kernel<W, S>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((p2n_fps_pruned_kernel<W, S>), dim3(B), dim3(W * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+static int fps_pruned_run(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, void *scratch, hipStream_t s) {
+    P2N_REQUIRE(((uintptr_t)scratch & 15) == 0, "p2n_fps: workspace must be 16-byte aligned");
+    const int ntiles = (N + 63) / 64;
+    float4 *sorted = (float4 *)scratch;
+    float4 *boxes = (float4 *)((char *)scratch + (((size_t)B * ntiles * 64 * sizeof(float4) + 255) & ~(size_t)255));
+    const size_t lds = (size_t)KS_BIN_WORDS * sizeof(int);
+    if (lds > 48 * 1024)
+        P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&p2n_knn_sort_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ps = p2n_prof_begin(P2N_K_FPS, s);
+    hipLaunchKernelGGL(p2n_knn_sort_kernel, dim3(B), dim3(KS_THREADS), lds, s, xyz, N, ntiles, sorted, boxes);
+    FpsPrArgs a = {xyz, sorted, boxes, idx, N, M, ntiles, start_idx};
+    int W, S;
+    fps_pruned_shape(N, &W, &S);
+    hipError_t e = hipErrorInvalidValue;
+    if (W == 4 && S == 8) e = fps_pruned_launch<4, 8>(a, B, s);
+    else if (W == 4 && S == 16) e = fps_pruned_launch<4, 16>(a, B, s);
+    else if (W == 4 && S == 24) e = fps_pruned_launch<4, 24>(a, B, s);
+    else if (W == 4 && S == 32) e = fps_pruned_launch<4, 32>(a, B, s);
+    else if (W == 8 && S == 8) e = fps_pruned_launch<8, 8>(a, B, s);
+    else if (W == 8 && S == 16) e = fps_pruned_launch<8, 16>(a, B, s);
+    else if (W == 16 && S == 8) e = fps_pruned_launch<16, 8>(a, B, s);
+    else if (W == 16 && S == 12) e = fps_pruned_launch<16, 12>(a, B, s);
+    else e = fps_pruned_launch<8, 24>(a, B, s);
+    p2n_prof_end(ps, s);
+    P2N_CHECK_HIP(e);
+    return P2N_OK;
 }
 
 // The wave-resident candidate list holds one 64-bit key per lane, (distance bits << 32) | index:

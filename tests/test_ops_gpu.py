@@ -122,6 +122,46 @@ def test_fps_ties_duplicates_and_oversampling():
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("case", ["lattice", "duplicates", "blobs", "flat", "ragged", "oversample", "nan"])
+def test_fps_bucket_pruned_kernel_edge_cases(case):
+    """Clouds of 5,120..12,288 points take the bucket-pruned single-workgroup kernel (Morton-ordered copy, per-bucket
+    skip test): same indices as the oracle on exact ties, duplicates, degenerate extents, ragged tile counts, more
+    samples than distinct points, and a NaN coordinate."""
+    from oracle import oracle
+    from pointcloudsegmentation_amd import ops
+    rng = np.random.default_rng(11)
+    M, start = 300, 5
+    if case == "lattice":
+        xyz = _grid_cloud(2, 18)                                   # 5,832 lattice points: masses of exact ties
+    elif case == "duplicates":
+        base = _cloud(1, 1000, seed=3)
+        xyz = np.concatenate([base] * 7, axis=1)                   # every point seven times
+        xyz = xyz[:, rng.permutation(xyz.shape[1])]
+        M = 1200                                                   # beyond the 1,000 distinct points: all-zero distances, lowest index
+    elif case == "blobs":
+        c = rng.standard_normal((1, 12, 3)).astype(np.float32) * 3
+        xyz = (c[:, rng.integers(0, 12, 9000)] + 0.01 * rng.standard_normal((1, 9000, 3))).astype(np.float32)
+    elif case == "flat":
+        xyz = _cloud(2, 6000, seed=8)
+        xyz[:, :, 2] = 0.25                                        # zero extent in z
+        xyz[1, :, 1] = -1.0                                        # a line
+    elif case == "ragged":
+        xyz = _cloud(3, 12288 - 37, seed=9)                        # last tile partly filled, 192 buckets
+        M, start = 500, 12250
+    elif case == "oversample":
+        xyz = _cloud(1, 5120, seed=10)
+        M = 5120                                                   # every point is selected exactly once
+    else:
+        xyz = _cloud(1, 7000, seed=12)
+        xyz[0, 4321, 1] = np.nan
+        M = 64
+    want = oracle.fps(xyz, M, start)
+    got = ops.farthest_point_sample(torch.from_numpy(np.ascontiguousarray(xyz)).cuda(), M, start).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    if case == "oversample":
+        assert sorted(got[0].tolist()) == list(range(5120))
+
+
 def test_fps_errors():
     from pointcloudsegmentation_amd import ops
     x = torch.zeros(1, 10, 3, device="cuda")
