@@ -114,6 +114,17 @@ int p2n_train_forward(const float *x, int B, int N, int feature_dim, int embeddi
 int p2n_train_backward(const float *x, const float *gemb, int B, int N, int feature_dim, int embedding_dim,
                        const void *const *params_host, void *const *grads_host,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* The same two calls in the opt-in bf16 mode (BASELINE north star: "bf16/fp32 MFMA GEMMs", 2e-2): the operands of every
+ * GEMM of reference point2net.py:36-48,57-65 and of its backward are rounded to bf16 in the loaders and multiplied on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; BatchNorm statistics, everything stored and all gradients stay
+ * fp32.  Same arguments and workspace; a forward and its backward must use the same precision.  Python:
+ * model.precision = "bf16". */
+int p2n_train_forward_bf16(const float *x, int B, int N, int feature_dim, int embedding_dim,
+                           const void *const *params_host, float momentum, float *emb, float *global_f,
+                           float *f1, float *f2, float *f3, void *workspace, size_t workspace_bytes, void *stream);
+int p2n_train_backward_bf16(const float *x, const float *gemb, int B, int N, int feature_dim, int embedding_dim,
+                            const void *const *params_host, void *const *grads_host,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* Shared MLP of a hierarchical level in train() mode (no reference counterpart: the north star names
  * set-abstraction / feature-propagation levels, the reference has none; semantics = torch's

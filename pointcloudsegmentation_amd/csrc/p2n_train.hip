@@ -21,6 +21,11 @@
 #include "p2n_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// Opt-in bf16 mode of the GEMMs (p2n_train_forward_bf16 / p2n_train_backward_bf16: the north star's "bf16/fp32 MFMA GEMMs",
+// 2e-2): operands are rounded to bf16 in the loaders, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16; everything
+// stored (activations, statistics, gradients) stays fp32, so the kernels become HBM-bound instead of MFMA-bound.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define BN_EPS 1e-5
 
 enum { LD_X = 0, LD_BNRELU = 1, LD_BNBWD = 2, LD_EMBGRAD = 3, LD_PLAIN = 4 };
@@ -40,6 +45,28 @@ __global__ void p2n_pack_w_kernel(const float *__restrict__ W, int ldw, int col0
     float v = 0.f;
     if (row < rows_real && k < k_real) v = trans ? W[(long)k * ldw + col0 + row] : W[(long)row * ldw + col0 + k];
     img[i] = v;
+}
+
+// bf16 image: fragment f = (kt*CT + ct)*2 + s covers k = 32kt + 16s .. +15: img[f][lane][i] (8 bf16 = 16 bytes per lane) =
+// M[32ct + (lane&31)][32kt + 16s + 8(lane>>5) + i].  Same 1-KiB fragments, half as many.
+__global__ void p2n_pack_w_bf16_kernel(const float *__restrict__ W, int ldw, int col0, int rows_real, int k_real, int trans,
+                                       __bf16 *__restrict__ img, int CT, int KT) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)CT * KT * 2 * 512) return;
+    const int e = (int)(i & 511), lane = e >> 3, j = e & 7;
+    const int f = (int)(i >> 9);
+    const int sx = f & 1, ct = (f >> 1) % CT, kt = (f >> 1) / CT;
+    const int row = 32 * ct + (lane & 31), k = 32 * kt + 16 * sx + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (row < rows_real && k < k_real) v = trans ? W[(long)k * ldw + col0 + row] : W[(long)row * ldw + col0 + k];
+    img[i] = (__bf16)v;
+}
+
+// first of the four rows (k0 .. k0+3) that register group g of lane half h holds in k-tile kt: fp32 MFMA operands take
+// k = 8g + 4h + j, the bf16 ones k = 16(g>>1) + 8h + 4(g&1) + j (registers 8s .. 8s+7 = the fragment of k-step s)
+template <bool BF>
+__device__ __forceinline__ int tl_k0(int kt, int g, int h) {
+    return BF ? 32 * kt + 16 * (g >> 1) + 8 * h + 4 * (g & 1) : 32 * kt + 8 * g + 4 * h;
 }
 
 // ---------------------------------------------------------------- layer GEMM (forward / dgrad)
@@ -76,11 +103,11 @@ __device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *
 // are read from the last real row(s) instead: the weight image is zero there, and so is the BatchNorm table, so
 // whatever finite value arrives contributes nothing.  Channel-major operands have Ppad columns in memory, all finite
 // (every producer writes its pad columns); point-major ones are clamped to the last point.
-template <int MODE, bool k4>
+template <int MODE, bool k4, bool BF>
 __device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bool valid, int h, f32x16 &r0, f32x16 &r1) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int k0 = 32 * kt + 8 * g + 4 * h;
+        const int k0 = tl_k0<BF>(kt, g, h);
         if (MODE == LD_X || MODE == LD_EMBGRAD) {   // point-major rows (P, ld)
             const long pc = pg < A.P ? pg : A.P - 1;
 #pragma unroll
@@ -113,14 +140,14 @@ __device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bo
 // dz = A1*dy + A2 + A3*z with dy = da masked by relu(bn(z)) > 0.  tab = per-k constants in LDS, zero for k >= K, and
 // the fetch delivered zeros there: those rows come out as zero without a test (relu(0*0+0) = 0; 0*0 + (0*0 + 0) = 0).
 // Pad columns (p >= P) come out finite and are never read by a reduction.
-template <int MODE>
+template <int MODE, bool BF>
 __device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool valid, int h, const float *tab, int KP,
                                                const f32x16 &r0, const f32x16 &r1) {
     if (MODE == LD_X || MODE == LD_EMBGRAD || MODE == LD_PLAIN) return r0;   // LD_PLAIN: a raw channel-major operand (K, Ppad)
     f32x16 out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int k0 = 32 * kt + 8 * g + 4 * h;
+        const int k0 = tl_k0<BF>(kt, g, h);
         const f32x4 s = *reinterpret_cast<const f32x4 *>(&tab[k0]);
         const f32x4 t = *reinterpret_cast<const f32x4 *>(&tab[KP + k0]);
         f32x4 a1, a2, a3;
@@ -144,11 +171,11 @@ __device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool 
 }
 
 // dz of k-tile kt back over da (same rows, this lane's column): every element was read by this lane only
-template <bool k4>
+template <bool k4, bool BF>
 __device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg, int h, const f32x16 &v) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int k0 = 32 * kt + 8 * g + 4 * h;
+        const int k0 = tl_k0<BF>(kt, g, h);
         if (k4) {
             if (k0 < A.K) {
                 float *d = A.dz_out + (long)k0 * A.Ppad + pg;
@@ -169,11 +196,12 @@ __device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg,
 // in the other LDS buffer by LDS-DMA (chunk = 32 fragments = 8/CT k-tiles).
 // K4: the reduction length is a multiple of four (every layer of the model; only first layers of hierarchical levels
 // are not), so the row bound is tested per group of four rows.
-template <int MODE, int CT, bool OUT_PM, bool K4>
+template <int MODE, int CT, bool OUT_PM, bool K4, bool BF = false>
 __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
     __shared__ __attribute__((aligned(16))) float wbuf[2 * TL_CHUNK_FLOATS];
     __shared__ __attribute__((aligned(16))) float tab[5 * 256];
-    constexpr int KPC = 8 / CT;   // k-tiles per weight chunk
+    constexpr int FPK = BF ? 2 * CT : 4 * CT;   // 1-KiB weight fragments per k-tile
+    constexpr int KPC = 32 / FPK;   // k-tiles per weight chunk
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int p = lane & 31, h = lane >> 5;
     const long pg = ((long)blockIdx.x * 4 + wave) * 32 + p;
@@ -190,36 +218,50 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
         }
     }
     f32x16 r0, r1;
-    tl_fetch<MODE, K4>(A, 0, pg, valid, h, r0, r1);
+    tl_fetch<MODE, K4, BF>(A, 0, pg, valid, h, r0, r1);
     f32x16 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
     p2n_dma_barrier();   // tab visible (and chunk 0 landed)
-    f32x16 cur = tl_transform<MODE>(A, 0, valid, h, tab, KP, r0, r1);
-    if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4>(A, 0, pg, h, cur);
+    f32x16 cur = tl_transform<MODE, BF>(A, 0, valid, h, tab, KP, r0, r1);
+    if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4, BF>(A, 0, pg, h, cur);
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         if (kt % KPC == 0) {
             if (kt) p2n_dma_barrier();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
             tl_stage(A.wimg, wbuf, kt / KPC + 1, wave, lane);
         }
-        if (kt + 1 < KT) tl_fetch<MODE, K4>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
-        const float *wb = wbuf + ((kt / KPC) & 1) * TL_CHUNK_FLOATS + (kt % KPC) * (CT * 4 * 256) + lane * 4;
+        if (kt + 1 < KT) tl_fetch<MODE, K4, BF>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
+        const float *wb = wbuf + ((kt / KPC) & 1) * TL_CHUNK_FLOATS + (kt % KPC) * (FPK * 256) + lane * 4;
+        if (BF) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 w[CT];
+            for (int sx = 0; sx < 2; ++sx) {
+                bf16x8 bfrag;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const f32x4 *>(wb + (ct * 4 + g) * 256);
+                for (int i = 0; i < 8; ++i) bfrag[i] = (__bf16)cur[8 * sx + i];
+                bf16x8 w[CT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const bf16x8 *>(wb + (ct * 2 + sx) * 256);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA32(w[ct][j], cur[4 * g + j], acc[ct]);
+                for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMAB(w[ct], bfrag, acc[ct]);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const f32x4 *>(wb + (ct * 4 + g) * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA32(w[ct][j], cur[4 * g + j], acc[ct]);
+            }
         }
         if (kt + 1 < KT) {
-            cur = tl_transform<MODE>(A, kt + 1, valid, h, tab, KP, r0, r1);
-            if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4>(A, kt + 1, pg, h, cur);
+            cur = tl_transform<MODE, BF>(A, kt + 1, valid, h, tab, KP, r0, r1);
+            if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4, BF>(A, kt + 1, pg, h, cur);
         }
     }
     const int cloud = valid ? (int)(pg / A.N) : 0;
@@ -356,13 +398,16 @@ __device__ __forceinline__ WgConst wgrad_const(const float *__restrict__ tab, in
     return c;
 }
 
-template <int MODE>
+#define WG_LDB (WG_PTS + 8)   // bf16 mode: row stride in bf16 elements (144 bytes: 16-byte fragments stay aligned)
+template <int MODE, bool BF>
 __device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__restrict__ dst, const WgConst &c,
                                            int row0, int nrows, long p0, long pend) {
     const int t = threadIdx.x;
+    __bf16 *dstb = reinterpret_cast<__bf16 *>(dst);
     if (MODE == LD_BNBWD || MODE == LD_BNRELU || MODE == LD_PLAIN) {
         const int r = t >> 2, seg = (t & 3) * 16;
         const bool rok = row0 + r < nrows;
+        bf16x8 ob;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long p = p0 + seg + 4 * i;
@@ -381,19 +426,29 @@ __device__ __forceinline__ void wgrad_park(const WgStage<MODE> &st, float *__res
                 }
                 o[j] = (rok && p + j < pend) ? v : 0.f;
             }
-            *reinterpret_cast<f32x4 *>(dst + r * WG_LD + seg + 4 * i) = o;
+            if (BF) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ob[4 * (i & 1) + j] = (__bf16)o[j];
+                if (i & 1) *reinterpret_cast<bf16x8 *>(dstb + r * WG_LDB + seg + 8 * (i >> 1)) = ob;
+            } else {
+                *reinterpret_cast<f32x4 *>(dst + r * WG_LD + seg + 4 * i) = o;
+            }
         }
     } else {
         const int r = t & 63, seg = (t >> 6) * 16;
         const bool rok = row0 + r < nrows;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[r * WG_LD + seg + i] = (rok && p0 + seg + i < pend) ? st.v0[i >> 2][i & 3] : 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const float v = (rok && p0 + seg + i < pend) ? st.v0[i >> 2][i & 3] : 0.f;
+            if (BF) dstb[r * WG_LDB + seg + i] = (__bf16)v;
+            else dst[r * WG_LD + seg + i] = v;
+        }
     }
 }
 
 // RT x CT MFMA tiles per wave: the workgroup's block of dW is (64 RT) x (64 CT).  128 x 128 blocks
 // halve the operand re-reads of the big layers (the 64 x 64 version was bound by L2/HBM traffic).
-template <int AMODE, int BMODE, int RT, int CT>
+template <int AMODE, int BMODE, int RT, int CT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void p2n_wgrad_kernel(WgArgs A) {   // two workgroups per CU: one parks its next block while the other multiplies
     __shared__ __attribute__((aligned(16))) float sa[RT * WG_TILE * WG_LD], sb[CT * WG_TILE * WG_LD];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
@@ -428,10 +483,10 @@ __global__ __launch_bounds__(256, 2) void p2n_wgrad_kernel(WgArgs A) {   // two 
     auto park = [&](long p0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
-            wgrad_park<AMODE>(sta[i], sa + i * WG_TILE * WG_LD, ca[i], (br * RT + i) * WG_TILE, A.rows, p0, s1);
+            wgrad_park<AMODE, BF>(sta[i], sa + i * WG_TILE * WG_LD, ca[i], (br * RT + i) * WG_TILE, A.rows, p0, s1);
 #pragma unroll
         for (int k = 0; k < CT; ++k)
-            wgrad_park<BMODE>(stb[k], sb + k * WG_TILE * WG_LD, cb[k], (bc * CT + k) * WG_TILE, A.cols, p0, s1);
+            wgrad_park<BMODE, BF>(stb[k], sb + k * WG_TILE * WG_LD, cb[k], (bc * CT + k) * WG_TILE, A.cols, p0, s1);
     };
     if (s0 < s1) {
         fetch(s0);
@@ -444,6 +499,29 @@ __global__ __launch_bounds__(256, 2) void p2n_wgrad_kernel(WgArgs A) {   // two 
         __syncthreads();   // the block of step p0 is in LDS
         const bool more = p0 + WG_PTS < s1;
         if (more) fetch(p0 + WG_PTS);   // in flight while the MFMAs run
+        if (BF) {
+            // tile i of the A block starts at sa + i*WG_TILE*WG_LD floats (the park's base), rows of WG_LDB bf16 inside
+#pragma unroll
+            for (int ks = 0; ks < WG_PTS / 16; ++ks) {
+                bf16x8 av[RT], bv[CT];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const int tile32 = wr * RT + i;   // 32-row tile of the block: 64-row park tile tile32/2, half tile32%2
+                    av[i] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(sa + (tile32 / 2) * WG_TILE * WG_LD) +
+                                                              (32 * (tile32 % 2) + r) * WG_LDB + 8 * h + 16 * ks);
+                }
+#pragma unroll
+                for (int k = 0; k < CT; ++k) {
+                    const int tile32 = wc * CT + k;
+                    bv[k] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(sb + (tile32 / 2) * WG_TILE * WG_LD) +
+                                                              (32 * (tile32 % 2) + r) * WG_LDB + 8 * h + 16 * ks);
+                }
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int k = 0; k < CT; ++k) acc[i][k] = MFMAB(av[i], bv[k], acc[i][k]);
+            }
+        } else {
 #pragma unroll
         for (int G = 0; G < WG_PTS / 8; ++G) {
             f32x4 av[RT], bv[CT];
@@ -457,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void p2n_wgrad_kernel(WgArgs A) {   // two 
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int k = 0; k < CT; ++k) acc[i][k] = MFMA32(av[i][j], bv[k][j], acc[i][k]);
+        }
         }
         if (more) {
             __syncthreads();   // everybody has read this step's block
@@ -807,8 +886,15 @@ int ct_pad(int rows) {   // output tiles rounded up to a power of two (the kerne
     return ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
 }
 
-int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float *img, hipStream_t s) {
+int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float *img, hipStream_t s, bool bf = false) {
     const int CT = ct_pad(rows), KT = (k + 31) / 32;
+    if (bf) {
+        const long n = (long)CT * KT * 2 * 512;
+        hipLaunchKernelGGL(p2n_pack_w_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, col0, rows, k,
+                           trans, reinterpret_cast<__bf16 *>(img), CT, KT);
+        P2N_CHECK_HIP(hipGetLastError());
+        return P2N_OK;
+    }
     const long n = (long)CT * KT * 4 * 256;
     hipLaunchKernelGGL(p2n_pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, col0, rows, k, trans,
                        img, CT, KT);
@@ -816,29 +902,34 @@ int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float 
     return P2N_OK;
 }
 
-template <int MODE, bool PM>
-int launch_layer(LayerArgs a, hipStream_t s) {
+template <int MODE, bool PM, bool BF>
+int launch_layer_p(LayerArgs a, hipStream_t s) {
     const dim3 grid(a.Ppad / 128), blk(256);
     a.KT = (a.K + 31) / 32;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_GEMM, s);
     if (a.K % 4 == 0) {
         switch (ct_pad(a.rows)) {
-            case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM, true>), grid, blk, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM, true>), grid, blk, 0, s, a); break;
-            case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM, true>), grid, blk, 0, s, a); break;
-            default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM, true>), grid, blk, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM, true, BF>), grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM, true, BF>), grid, blk, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM, true, BF>), grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM, true, BF>), grid, blk, 0, s, a); break;
         }
     } else {
         switch (ct_pad(a.rows)) {
-            case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM, false>), grid, blk, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM, false>), grid, blk, 0, s, a); break;
-            case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM, false>), grid, blk, 0, s, a); break;
-            default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM, false>), grid, blk, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM, false, BF>), grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM, false, BF>), grid, blk, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 4, PM, false, BF>), grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 8, PM, false, BF>), grid, blk, 0, s, a); break;
         }
     }
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
+}
+
+template <int MODE, bool PM>
+int launch_layer(LayerArgs a, hipStream_t s, bool bf = false) {
+    return bf ? launch_layer_p<MODE, PM, true>(a, s) : launch_layer_p<MODE, PM, false>(a, s);
 }
 
 int wgrad_slice(int P, int blocks) {
@@ -851,26 +942,31 @@ int wgrad_slice(int P, int blocks) {
     return (int)sl;
 }
 
-template <int AM, int BM, int RT, int CT>
+template <int AM, int BM, int RT, int CT, bool BF>
 int launch_wgrad_rc(WgArgs a, hipStream_t s) {
     const int ntr = (a.rows + 64 * RT - 1) / (64 * RT);
     a.ntc = (a.cols + 64 * CT - 1) / (64 * CT);
     a.slice = wgrad_slice(a.P, ntr * a.ntc);
     const long nsl = ((long)a.P + a.slice - 1) / a.slice;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_WGRAD, s);
-    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM, RT, CT>), dim3(ntr * a.ntc, (unsigned)nsl), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((p2n_wgrad_kernel<AM, BM, RT, CT, BF>), dim3(ntr * a.ntc, (unsigned)nsl), dim3(256), 0, s, a);
     p2n_prof_end(ps, s);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
 
-template <int AM, int BM>
-int launch_wgrad(WgArgs a, hipStream_t s) {
+template <int AM, int BM, bool BF>
+int launch_wgrad_p(WgArgs a, hipStream_t s) {
     const bool r2 = a.rows >= 128, c2 = a.cols >= 128;
-    if (r2 && c2) return launch_wgrad_rc<AM, BM, 2, 2>(a, s);
-    if (r2) return launch_wgrad_rc<AM, BM, 2, 1>(a, s);
-    if (c2) return launch_wgrad_rc<AM, BM, 1, 2>(a, s);
-    return launch_wgrad_rc<AM, BM, 1, 1>(a, s);
+    if (r2 && c2) return launch_wgrad_rc<AM, BM, 2, 2, BF>(a, s);
+    if (r2) return launch_wgrad_rc<AM, BM, 2, 1, BF>(a, s);
+    if (c2) return launch_wgrad_rc<AM, BM, 1, 2, BF>(a, s);
+    return launch_wgrad_rc<AM, BM, 1, 1, BF>(a, s);
+}
+
+template <int AM, int BM>
+int launch_wgrad(WgArgs a, hipStream_t s, bool bf = false) {
+    return bf ? launch_wgrad_p<AM, BM, true>(a, s) : launch_wgrad_p<AM, BM, false>(a, s);
 }
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -896,9 +992,9 @@ static int check_common(const char *fn, int B, int N, int F, int E) {
 // (W,b,[gamma,beta,running_mean,running_var]) x layers; running stats are updated in place.
 // momentum < 0: eval-mode BatchNorm for a differentiable forward -- the layers normalise with the
 // running statistics, which stay untouched; p2n_train_backward on the same workspace follows suit.
-extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, const void *const *params_host,
-                                 float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
-                                 void *workspace, size_t workspace_bytes, void *stream_) {
+static int train_forward_run(bool bf, const float *x, int B, int N, int F, int E, const void *const *params_host,
+                             float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
+                             void *workspace, size_t workspace_bytes, void *stream_) {
     TRY(check_common("p2n_train_forward", B, N, F, E));
     P2N_REQUIRE(x && params_host && emb, "p2n_train_forward: null pointer");
     P2N_REQUIRE(!f1 && !f2 && !f3, "p2n_train_forward: the training forward does not produce f1/f2/f3 (pass NULL; "
@@ -916,18 +1012,24 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
     hipStream_t s = (hipStream_t)stream_;
     const bool eval_stats = momentum < 0.f;   // eval-mode BatchNorm: running statistics, not updated
     P2N_CHECK_HIP(hipMemsetAsync(n.mode, eval_stats ? 1 : 0, sizeof(int), s));   // the backward reads it on the device
+    // bf16 mode: the first three layers (K = 6, 64, 64: 10 % of the forward's FLOPs) stay on the fp32 MFMA -- they carry
+    // the coordinates' precision, and rounding them to bf16 doubles the deviation of the embeddings (2.5e-2 -> 1.3e-2 of
+    // max|emb| against the fp32 mode) for 0.05 ms; the backward runs all of its GEMMs in bf16.
+    const int bf_l0 = 3;
+    const bool bf_all = bf;
     for (int l = 0; l < 9; ++l) {
         const int K = (l == 6) ? 256 : n.cin[l];
-        TRY(pack_w(n.W[l], n.cin[l], 0, n.cout[l], K, 0, n.wimg, s));
+        bf = bf_all && l >= bf_l0;
+        TRY(pack_w(n.W[l], n.cin[l], 0, n.cout[l], K, 0, n.wimg, s, bf));
         LayerArgs a = {};
         a.wimg = n.wimg; a.bias = n.b[l]; a.K = K; a.rows = n.cout[l];
         a.P = n.P; a.Ppad = n.Ppad; a.N = n.N;
-        if (l == 0) { a.in0 = x; a.ld = F; a.out = n.z[0]; TRY((launch_layer<LD_X, false>(a, s))); }
+        if (l == 0) { a.in0 = x; a.ld = F; a.out = n.z[0]; TRY((launch_layer<LD_X, false>(a, s, bf))); }
         else {
             a.in0 = n.z[l - 1]; a.tab = n.ftab[l - 1];
             if (l == 6) a.bias_cloud = n.bias6c;
-            if (l == 8) { a.out = emb; a.ld = E; TRY((launch_layer<LD_BNRELU, true>(a, s))); }
-            else { a.out = n.z[l]; TRY((launch_layer<LD_BNRELU, false>(a, s))); }
+            if (l == 8) { a.out = emb; a.ld = E; TRY((launch_layer<LD_BNRELU, true>(a, s, bf))); }
+            else { a.out = n.z[l]; TRY((launch_layer<LD_BNRELU, false>(a, s, bf))); }
         }
         if (l == 8) break;
         if (eval_stats) {
@@ -955,9 +1057,9 @@ extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, con
 
 // Backward of p2n_train_forward (same workspace, untouched in between).  grads_host: HOST
 // array of 34 DEVICE pointers (W,b,[gamma,beta]) x layers, each fully overwritten.
-extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int N, int F, int E,
-                                  const void *const *params_host, void *const *grads_host, void *workspace,
-                                  size_t workspace_bytes, void *stream_) {
+static int train_backward_run(bool bf, const float *x, const float *gemb, int B, int N, int F, int E,
+                              const void *const *params_host, void *const *grads_host, void *workspace,
+                              size_t workspace_bytes, void *stream_) {
     TRY(check_common("p2n_train_backward", B, N, F, E));
     P2N_REQUIRE(x && gemb && params_host && grads_host, "p2n_train_backward: null pointer");
     Net n;
@@ -1018,12 +1120,12 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
         WgArgs w = {};
         w.a0 = gemb; w.ld_a = E; w.b0 = n.z[7]; w.btab = n.ftab[7]; w.dW = dW[8];
         w.rows = E; w.cols = 128; w.ldw = 128; w.P = n.P; w.Ppad = n.Ppad;
-        TRY((launch_wgrad<LD_EMBGRAD, LD_BNRELU>(w, s)));
-        TRY(pack_w(n.W[8], 128, 0, 128, E, 1, n.wimg, s));
+        TRY((launch_wgrad<LD_EMBGRAD, LD_BNRELU>(w, s, bf)));
+        TRY(pack_w(n.W[8], 128, 0, 128, E, 1, n.wimg, s, bf));
         LayerArgs a = {};
         a.in0 = gemb; a.ld = E; a.wimg = n.wimg; a.K = E; a.rows = 128;
         a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[0];
-        TRY((launch_layer<LD_EMBGRAD, false>(a, s)));
+        TRY((launch_layer<LD_EMBGRAD, false>(a, s, bf)));
     }
     int cur = 0;   // n.da[cur] holds da_l for the layer being processed
     for (int l = 7; l >= 0; --l) {
@@ -1041,22 +1143,22 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
             w.a0 = n.da[cur]; w.a1 = n.z[0]; w.atab = n.btab; w.dW = dW[0];
             w.rows = C; w.ldw = n.cin[0]; w.P = n.P; w.Ppad = n.Ppad;
             w.b0 = x; w.ld_b = F; w.cols = F;
-            TRY((launch_wgrad<LD_BNBWD, LD_X>(w, s)));
+            TRY((launch_wgrad<LD_BNBWD, LD_X>(w, s, bf)));
             break;
         }
         // data gradient first: da_{l-1} = W_l^T . dz_l, and its loader leaves dz_l in place of da_l
         const int rows = (l == 6) ? 256 : n.cin[l];
-        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, s));
+        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, s, bf));
         LayerArgs a = {};
         a.in0 = n.da[cur]; a.in1 = n.z[l]; a.tab = n.btab; a.wimg = n.wimg; a.K = C; a.rows = rows;
         a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[cur ^ 1]; a.dz_out = n.da[cur];
-        TRY((launch_layer<LD_BNBWD, false>(a, s)));
+        TRY((launch_layer<LD_BNBWD, false>(a, s, bf)));
         // weight gradient from dz_l (one tensor, no transform on that side)
         WgArgs w = {};
         w.a0 = n.da[cur]; w.dW = dW[l];
         w.rows = C; w.ldw = n.cin[l]; w.P = n.P; w.Ppad = n.Ppad;
         w.b0 = n.z[l - 1]; w.btab = n.ftab[l - 1]; w.cols = (l == 6) ? 256 : n.cin[l];
-        TRY((launch_wgrad<LD_PLAIN, LD_BNRELU>(w, s)));
+        TRY((launch_wgrad<LD_PLAIN, LD_BNRELU>(w, s, bf)));
         if (l == 6) {
             // global branch: per-cloud sums of dz6 -> dW6[:,256:] and dg
             StatArgs sc = st;
@@ -1076,6 +1178,37 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
         }
     }
     return P2N_OK;
+}
+
+
+extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, const void *const *params_host,
+                                 float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
+                                 void *workspace, size_t workspace_bytes, void *stream_) {
+    return train_forward_run(false, x, B, N, F, E, params_host, momentum, emb, global_f, f1, f2, f3, workspace, workspace_bytes,
+                             stream_);
+}
+
+extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int N, int F, int E,
+                                  const void *const *params_host, void *const *grads_host, void *workspace,
+                                  size_t workspace_bytes, void *stream_) {
+    return train_backward_run(false, x, gemb, B, N, F, E, params_host, grads_host, workspace, workspace_bytes, stream_);
+}
+
+// The same two calls with the operands of every GEMM (layer outputs, data and weight gradients) rounded to bf16 and
+// multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; BatchNorm statistics, the global max, the small
+// global-branch products and everything stored stay fp32.  Same workspace, same arguments; a forward and its
+// backward must use the same precision.
+extern "C" int p2n_train_forward_bf16(const float *x, int B, int N, int F, int E, const void *const *params_host,
+                                      float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
+                                      void *workspace, size_t workspace_bytes, void *stream_) {
+    return train_forward_run(true, x, B, N, F, E, params_host, momentum, emb, global_f, f1, f2, f3, workspace, workspace_bytes,
+                             stream_);
+}
+
+extern "C" int p2n_train_backward_bf16(const float *x, const float *gemb, int B, int N, int F, int E,
+                                       const void *const *params_host, void *const *grads_host, void *workspace,
+                                       size_t workspace_bytes, void *stream_) {
+    return train_backward_run(true, x, gemb, B, N, F, E, params_host, grads_host, workspace, workspace_bytes, stream_);
 }
 
 // =========================================================================== generic shared MLP, train mode

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--global-batch", type=int, default=32)
     ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--bf16", action="store_true", help="model.precision = 'bf16': GEMM operands in bf16 (opt-in mode)")
     ap.add_argument("--no-prepare", action="store_true", help="do not start the loss's neighbour search beside the forward")
     ap.add_argument("--no-loss", action="store_true", help="loss = emb.sum() (model fwd+bwd only)")
     args = ap.parse_args()
@@ -45,6 +46,8 @@ def main():
     b = args.global_batch // world
     torch.manual_seed(0)
     model = Point2Net(6, 64).to(dev).train()
+    if args.bf16:
+        model.precision = "bf16"
     crit = InstanceSegLoss(64, 0.1, 0.5)
     # reference train.py:84-88 (Adam, lr 1e-4, weight_decay 1e-5); fused=True is torch's single-kernel implementation of it
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
@@ -84,7 +87,7 @@ def main():
         pts_step = args.global_batch * args.points
         print(json.dumps({"metric": "training step points/sec (global B=32 x 8192)", "value": pts_step * args.steps / dt,
                           "unit": "points/s", "n_gpus": world, "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,
-                          "scaling": "strong", "dtype": "f32", "data": "synthetic", "loss": float(loss),
+                          "scaling": "strong", "dtype": "bf16 GEMM operands, f32 accumulate/store" if args.bf16 else "f32", "data": "synthetic", "loss": float(loss),
                           "config": {"workload": "train fwd + InstanceSegLoss + bwd + grad all-reduce + clip + Adam"
                                      if not args.no_loss else "train fwd + bwd (loss = emb.sum()) + all-reduce + Adam",
                                      "global_batch": args.global_batch, "points_per_cloud": args.points}}), flush=True)
