@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
     for (int kt = 0; kt < KT; ++kt) {
         if (kt % KPC == 0) {
             if (kt) p2n_dma_barrier();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
-            tl_stage(A.wimg, wbuf, kt / KPC + 1, wave, lane);
+            if ((kt / KPC + 1) * KPC < KT) tl_stage(A.wimg, wbuf, kt / KPC + 1, wave, lane);   // never a chunk nobody reads: nothing is pending when the workgroup ends
         }
         if (kt + 1 < KT) tl_fetch<MODE, K4, BF>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
         const float *wb = wbuf + ((kt / KPC) & 1) * TL_CHUNK_FLOATS + (kt % KPC) * (FPK * 256) + lane * 4;
@@ -316,7 +316,6 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
             }
         }
     }
-    p2n_dma_barrier();   // the spare chunk's DMA must land before the workgroup's LDS is released
 }
 
 // ---------------------------------------------------------------- wgrad: dW = dz . a^T over points
