@@ -49,3 +49,12 @@ def assert_close_to_max(got, ref, tol, what=""):
     assert err <= tol, f"{what}: max|diff|/max|ref| = {err:.3e} > {tol:.1e}"
     assert rel <= 1e3 * tol, f"{what}: element-wise relative error {rel:.3e} > {1e3 * tol:.1e}"
     return err
+
+
+def free_port() -> int:
+    """A TCP port nobody listens on right now (bound to port 0 and released): a fixed or pid-derived port can belong
+    to another process on a shared box, and a rendezvous against a foreign listener hangs instead of failing."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the data-parallel training step (flat-bucket gradient
 all-reduce).  Equal shards: the averaged gradients equal the mean of the two ranks'
 single-process gradients, parameters stay identical across ranks after the step."""
+import datetime
 import os
 import sys
 
@@ -8,7 +9,7 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from conftest import REPO
+from conftest import REPO, free_port
 
 
 def _make(seed=0):
@@ -30,7 +31,7 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     from pointcloudsegmentation_amd.parallel import sync_bn_buffers, train_step
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     m, crit, opt = _make()
     x, y = _data(rank)
     out = train_step(m, crit, opt, x, y)
@@ -42,7 +43,7 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_two_rank_training_step(tmp_path):
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")

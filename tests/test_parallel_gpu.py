@@ -4,6 +4,7 @@ tests/test_sharding_gloo.py check on CPU tensors.  Both ranks share the one GPU 
 child initialises it itself; the backend is gloo (RCCL needs one device per rank), so the collective moves the
 same flat gradient bucket the RCCL path moves.  No scaling curve is claimed from this: it proves the code path.
 """
+import datetime
 import os
 import sys
 
@@ -12,7 +13,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from conftest import REPO
+from conftest import REPO, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +37,7 @@ def _train_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from pointcloudsegmentation_amd import parallel
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     dev = torch.device("cuda", 0)
     m, crit = _make()
     m = m.to(dev)
@@ -54,7 +55,7 @@ def _train_worker(rank, world, port, out_dir):
 
 
 def test_two_rank_training_step_on_device_tensors(tmp_path):
-    port = 33500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
@@ -90,7 +91,7 @@ def _infer_worker(rank, world, port, out_path):
     from pointcloudsegmentation_amd.sharding import infer_sharded
     from pointcloudsegmentation_amd.synth import make_batch
     from src.models.point2net import Point2Net
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     torch.manual_seed(0)
     model = Point2Net(6, 64).eval().to("cuda:0")
     scenes = [torch.from_numpy(make_batch(1, n, seed=n)[0]) for n in (5000, 1310, 640, 20000, 333)]
@@ -106,7 +107,7 @@ def test_two_rank_sharded_inference_on_device_tensors(tmp_path):
     from pointcloudsegmentation_amd.synth import make_batch
     from src.models.point2net import Point2Net
     out = str(tmp_path / "res.pt")
-    port = 35500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_infer_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out)
     torch.manual_seed(0)

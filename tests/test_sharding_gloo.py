@@ -1,5 +1,6 @@
 """CPU, world_size 2 over gloo: the N>1 path of the scene-sharded inference
  -- partition is exact, results equal the single-process run."""
+import datetime
 import os
 import sys
 
@@ -8,7 +9,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from conftest import REPO
+from conftest import REPO, free_port
 
 
 def test_shard_indices_partition():
@@ -29,7 +30,7 @@ def _worker(rank, world, port, out_path):
     from pointcloudsegmentation_amd.sharding import infer_sharded
     from pointcloudsegmentation_amd.synth import make_batch
     from src.models.point2net import Point2Net
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     torch.manual_seed(0)
     torch.set_num_threads(2)
     model = Point2Net(6, 64).eval()
@@ -46,7 +47,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     from pointcloudsegmentation_amd.synth import make_batch
     from src.models.point2net import Point2Net
     out = str(tmp_path / "res.pt")
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out)
     torch.manual_seed(0)
