@@ -19,6 +19,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                 sequence (its Python files do not travel to the GPU box), timed on this host
   cpu_port      the CPU oracle (oracle/p2n_oracle.c, double accumulation) timed on this host
   fps           farthest-point sampling of one 40k-point scene (the metric's second half)
+  train         one training step (BASELINE.json configs[3]: train-mode forward + InstanceSegLoss + backward + clip + Adam)
+                at B=32 x 8192 on this GPU, ms per step in fp32 and in the opt-in bf16 mode (tools/bench_train.py)
   hier          the hierarchical sibling (FPS + ball query + shared MLPs + three-NN propagation) at the
                 same B=16 x N=8192: ms per forward and the shared-MLP kernels against the fp32 MFMA peak
 """
@@ -159,6 +161,52 @@ def bf16_leg(model, x, lib, steps):
             "note": "opt-in path (model.precision = 'bf16'); layers 0-2 split bf16, layers 3-8 bf16, epilogues fp32"}
 
 
+def train_leg(device, steps=10):
+    """BASELINE.json configs[3] on one GPU: ms per training step at B=32 x 8192, fp32 and the opt-in bf16 mode."""
+    from pointcloudsegmentation_amd.synth import make_batch, make_labels
+    from src.models.losses import InstanceSegLoss
+    from src.models.point2net import Point2Net
+    B, N = 32, N_POINTS
+    x = torch.from_numpy(make_batch(B, N, seed=200)).to(device)
+    y = torch.from_numpy(make_labels(B, N, seed=0)).to(device)
+    pts = x[:, :, :3].contiguous()
+    out = {"workload": "train fwd + InstanceSegLoss + bwd + clip_grad_norm_ + Adam (reference train.py:118-136), "
+                       "B=32 x 8192, random-init weights, synthetic labels", "steps": steps}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model = Point2Net(6, 64).to(device).train()
+        model.precision = prec
+        crit = InstanceSegLoss(64, 0.1, 0.5)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
+
+        def step():
+            opt.zero_grad()
+            crit.prepare(pts, y)
+            loss = crit(pts, model(x), y)["total_loss"]
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            opt.step()
+            return loss
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize(device)
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        assert bool(torch.isfinite(loss))
+        out[prec] = {"ms_per_step": ms, "points_per_s": B * N / (ms * 1e-3),
+                     "tflops_algorithmic": 3 * FLOP_PER_PT_STEP * B * N / (ms * 1e-3) / 1e12,
+                     "frac_of_fp32_mfma_peak": 3 * FLOP_PER_PT_STEP * B * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        del model, opt
+    del out["bf16"]["frac_of_fp32_mfma_peak"]   # HBM-bound in this mode (DESIGN.md section 7): the fp32 MFMA peak is not its roofline
+    out["bf16"]["note"] = "GEMM operands rounded to bf16, fp32 accumulation and storage"
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(kernel):
     """(HBM bytes per launch, provenance) of this workload's kernel from the committed PMC summary (counters
     cannot be read from inside the process); (None, None) when the file is absent.  The provenance names the
@@ -179,6 +227,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-fps", action="store_true", help="skip the FPS leg")
     ap.add_argument("--no-hier", action="store_true", help="skip the hierarchical-sibling leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,6 +325,8 @@ def main():
             out["bf16"] = bf16_leg(model, x, lib, args.steps)
             if not args.no_fps:
                 out["fps"] = fps_leg(device)
+            if not args.no_train:
+                out["train"] = train_leg(device)
             if not args.no_hier:
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import bench_hier
