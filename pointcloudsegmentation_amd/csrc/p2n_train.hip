@@ -84,15 +84,16 @@ struct LayerArgs {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
-#define TL_CHUNK_FLOATS (32 * 256)   // 32 fragments = 32 KiB
+#define TL_WGS(CT) ((CT) <= 4 ? 3 : 2)   // workgroups per CU the layer kernel is built for
 
-// this wave's 8 fragments of weight chunk c -> LDS buffer c&1 (LDS-DMA, lane-linear image)
+// this wave's quarter of weight chunk c (CHF fragments of 1 KiB) -> LDS buffer c&1 (LDS-DMA, lane-linear image)
+template <int CHF>
 __device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *wbuf, int c, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = wave * 8 + i;
-        __builtin_amdgcn_global_load_lds((gbl_void_t *)(wimg + ((long)c * 32 + f) * 256 + lane * 4),
-                                         (lds_void_t *)(wbuf + (c & 1) * TL_CHUNK_FLOATS + f * 256), 16, 0, 0);
+    for (int i = 0; i < CHF / 4; ++i) {
+        const int f = wave * (CHF / 4) + i;
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(wimg + ((long)c * CHF + f) * 256 + lane * 4),
+                                         (lds_void_t *)(wbuf + (c & 1) * (CHF * 256) + f * 256), 16, 0, 0);
     }
 }
 
@@ -197,17 +198,21 @@ __device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg,
 // K4: the reduction length is a multiple of four (every layer of the model; only first layers of hierarchical levels
 // are not), so the row bound is tested per group of four rows.
 template <int MODE, int CT, bool OUT_PM, bool K4, bool BF = false>
-__global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
-    __shared__ __attribute__((aligned(16))) float wbuf[2 * TL_CHUNK_FLOATS];
+__global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerArgs A) {
+    // Up to 128 output rows (64 accumulator registers): three workgroups per CU -- 16-KiB weight chunks keep the LDS of
+    // three within 160 KiB, the registers fit three waves per SIMD -- so that while two waves of a SIMD alternate
+    // their MFMA blocks a third is there for the phases between blocks.
+    constexpr int CHF = CT <= 4 ? 16 : 32;      // weight fragments (1 KiB) per chunk
+    __shared__ __attribute__((aligned(16))) float wbuf[2 * CHF * 256];
     __shared__ __attribute__((aligned(16))) float tab[5 * 256];
     constexpr int FPK = BF ? 2 * CT : 4 * CT;   // 1-KiB weight fragments per k-tile
-    constexpr int KPC = 32 / FPK;   // k-tiles per weight chunk
+    constexpr int KPC = CHF / FPK;   // k-tiles per weight chunk
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int p = lane & 31, h = lane >> 5;
     const long pg = ((long)blockIdx.x * 4 + wave) * 32 + p;
     const bool valid = pg < A.P;
     const int KT = A.KT, KP = KT * 32;
-    tl_stage(A.wimg, wbuf, 0, wave, lane);   // first weight chunk flies while the operands load
+    tl_stage<CHF>(A.wimg, wbuf, 0, wave, lane);   // first weight chunk flies while the operands load
     __shared__ __attribute__((aligned(16))) float bias_s[256];   // the epilogue's bias, zero without one
     if (threadIdx.x < CT * 32) bias_s[threadIdx.x] = (A.bias && (int)threadIdx.x < A.rows) ? A.bias[threadIdx.x] : 0.f;
     if (MODE == LD_BNRELU || MODE == LD_BNBWD) {
@@ -231,10 +236,10 @@ __global__ __launch_bounds__(256, 2) void p2n_train_layer_kernel(LayerArgs A) {
     for (int kt = 0; kt < KT; ++kt) {
         if (kt % KPC == 0) {
             if (kt) p2n_dma_barrier();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
-            if ((kt / KPC + 1) * KPC < KT) tl_stage(A.wimg, wbuf, kt / KPC + 1, wave, lane);   // never a chunk nobody reads: nothing is pending when the workgroup ends
+            if ((kt / KPC + 1) * KPC < KT) tl_stage<CHF>(A.wimg, wbuf, kt / KPC + 1, wave, lane);   // never a chunk nobody reads: nothing is pending when the workgroup ends
         }
         if (kt + 1 < KT) tl_fetch<MODE, K4, BF>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
-        const float *wb = wbuf + ((kt / KPC) & 1) * TL_CHUNK_FLOATS + (kt % KPC) * (FPK * 256) + lane * 4;
+        const float *wb = wbuf + ((kt / KPC) & 1) * (CHF * 256) + (kt % KPC) * (FPK * 256) + lane * 4;
         if (BF) {
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
