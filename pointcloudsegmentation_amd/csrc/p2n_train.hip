@@ -253,15 +253,26 @@ __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerA
                 for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMAB(w[ct], bfrag, acc[ct]);
             }
         } else {
+            // Tile-outer order: the four MFMAs of one output tile and one group of four k run back to back on the
+            // same accumulator (no penalty: tools/micro/mfma_rate.hip), and the fragment register of that tile is
+            // re-read for the next group right behind them -- seven tiles' MFMAs (1,800 cycles) before it is needed
+            // again, where the k-outer order had to wait for all CT reads at every group boundary with the pipe empty.
+            f32x4 w[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const f32x4 *>(wb + (ct * 4) * 256);
+            __builtin_amdgcn_sched_group_barrier(0x100, CT, 0);   // the CT reads of the first group, then 4 MFMA / 1 read
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 w[CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const f32x4 *>(wb + (ct * 4 + g) * 256);
+                for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) acc[ct] = MFMA32(w[ct][j], cur[4 * g + j], acc[ct]);
+                    for (int j = 0; j < 4; ++j) acc[ct] = MFMA32(w[ct][j], cur[4 * g + j], acc[ct]);
+                    if (g < 3) {
+                        w[ct] = *reinterpret_cast<const f32x4 *>(wb + (ct * 4 + g + 1) * 256);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+                    }
+                }
             }
         }
         if (kt + 1 < KT) {
