@@ -7,11 +7,14 @@
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 // XVAR (matrix waves): 0 back-to-back MFMAs, 1 `s_nop 0` behind each, 2 `s_sleep 1` behind every fourth,
-//                      3 as 0 with the sibling at priority 3, 4 `s_nop 7` behind each, 5 two VALU FMAs of its own behind each
+//                      3 as 0 with the sibling at priority 3, 4 `s_nop 7` behind each, 5 two VALU FMAs of its own behind each,
+//                      6 / 7 as 0 / 5 with v_mfma_f32_32x32x16_bf16
 // YKIND (sibling waves): 0 VALU chain, 1 global loads (16 B per lane, L2-resident), 2 LDS reads (16 B per lane)
 template <int XVAR, int YKIND, bool SWAP>
 __global__ __launch_bounds__(512) void duo(float *out, long long *cyc, int xiters, int yiters, const float *src) {
@@ -27,14 +30,20 @@ __global__ __launch_bounds__(512) void duo(float *out, long long *cyc, int xiter
         for (int i = 0; i < 4; ++i)
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         const float a = lane * 1e-3f, b = 1.0f + blockIdx.x;
+        bf16x8 ab[4], bb;
+        for (int e = 0; e < 8; ++e) {
+            bb[e] = (__bf16)(b + e);
+            for (int i = 0; i < 4; ++i) ab[i][e] = (__bf16)(a + i + e);
+        }
         t0 = __builtin_readcyclecounter();
         for (int it = 0; it < xiters; ++it) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[i] = MFMA32(a + (float)i, b, acc[i]);
-                    if (XVAR == 5) { own[i] = __builtin_fmaf(own[i], a, b); own[(i + 1) & 3] = __builtin_fmaf(own[(i + 1) & 3], b, a); }
+                    if (XVAR >= 6) acc[i] = MFMAB(ab[i], bb, acc[i]);
+                    else acc[i] = MFMA32(a + (float)i, b, acc[i]);
+                    if (XVAR == 5 || XVAR == 7) { own[i] = __builtin_fmaf(own[i], a, b); own[(i + 1) & 3] = __builtin_fmaf(own[(i + 1) & 3], b, a); }
                     if (XVAR == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); }
                     if (XVAR == 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0); }
                     if (XVAR == 2 && i == 3) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_sched_barrier(0); }
@@ -119,6 +128,9 @@ int main() {
     ROW(2, "s_sleep 1 behind every 4th")
     ROW(3, "back to back, sibling prio 3")
     ROW(5, "2 own FMAs behind each")
+    printf("v_mfma_f32_32x32x16_bf16 in place of the fp32 MFMA (same count)\n");
+    ROW(6, "bf16, back to back")
+    ROW(7, "bf16, 2 own FMAs behind each")
     printf("the same with the matrix waves the YOUNGER ones (waves 4..7; the siblings are waves 0..3)\n");
     if (run<0, 0, true>(out, cyc, src, "back to back", "VALU chain")) return 1;
     if (run<0, 1, true>(out, cyc, src, "back to back", "global loads")) return 1;
