@@ -86,14 +86,21 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 #define TL_WGS(CT) ((CT) <= 4 ? 3 : 2)   // workgroups per CU the layer kernel is built for
 
+// Buffer instructions state that split outright (resource = the row base in scalar registers, `offen` = the lane
+// offset); written as pointer arithmetic the compiler folds the lane offset into a 64-bit vector base ahead of the
+// loop and is back to one v_lshl_add_u64 per access.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tl_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);   // raw, unbounded, 32-bit data
+}
+
 // this wave's quarter of weight chunk c (CHF fragments of 1 KiB) -> LDS buffer c&1 (LDS-DMA, lane-linear image)
 template <int CHF>
 __device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *wbuf, int c, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < CHF / 4; ++i) {
-        const int f = wave * (CHF / 4) + i;
-        __builtin_amdgcn_global_load_lds((gbl_void_t *)(wimg + ((long)c * CHF + f) * 256 + lane * 4),
-                                         (lds_void_t *)(wbuf + (c & 1) * (CHF * 256) + f * 256), 16, 0, 0);
+        const int f = wave * (CHF / 4) + i;   // image offset on the scalar side, lane offset constant: no vector-ALU instruction
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(tl_rsrc(wimg), (lds_void_t *)(wbuf + (c & 1) * (CHF * 256) + f * 256), 16,
+                                                 lane * 16, (c * CHF + f) * 1024, 0, 0);
     }
 }
 
@@ -104,8 +111,27 @@ __device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *
 // are read from the last real row(s) instead: the weight image is zero there, and so is the BatchNorm table, so
 // whatever finite value arrives contributes nothing.  Channel-major operands have Ppad columns in memory, all finite
 // (every producer writes its pad columns); point-major ones are clamped to the last point.
+// k4 (reduction length a multiple of 8, of 16 in bf16 mode, rows of fewer than 2^26 columns): the address of a
+// channel-major element is a wave-uniform row base (scalar registers, scalar arithmetic) plus ONE constant 32-bit lane
+// offset `voffb` -- the lane half's rows and the lane's column, in bytes -- so a tile's loads and stores need no
+// vector-ALU instruction at all.  They matter: vector-ALU time adds to MFMA time on this chip.
+template <bool BF>
+__device__ __forceinline__ const float *tl_urow(const float *base, const LayerArgs &A, int kt, int g, long bbase) {
+    constexpr int HR = BF ? 8 : 4;               // rows between the two lane halves
+    const int ku = tl_k0<BF>(kt, g, 0);          // wave-uniform first row of the group (lane half 0)
+    const int kc = ku < A.K ? ku : A.K - 2 * HR; // past the extent: the last rows (finite; weights and table are zero there)
+    return base + (long)kc * A.Ppad + bbase;
+}
+__device__ __forceinline__ float tl_ldu(const float *urow, unsigned voffb) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(tl_rsrc(urow), (int)voffb, 0, 0));
+}
+__device__ __forceinline__ void tl_stu(float *urow, unsigned voffb, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tl_rsrc(urow), (int)voffb, 0, 0);
+}
+
 template <int MODE, bool k4, bool BF>
-__device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bool valid, int h, f32x16 &r0, f32x16 &r1) {
+__device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bool valid, int h, f32x16 &r0, f32x16 &r1,
+                                         long bbase, unsigned voffb) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int k0 = tl_k0<BF>(kt, g, h);
@@ -117,14 +143,13 @@ __device__ __forceinline__ void tl_fetch(const LayerArgs &A, int kt, long pg, bo
                 r0[4 * g + j] = A.in0[pc * A.ld + k];
             }
         } else if (k4) {
-            const int kc = k0 < A.K ? k0 : A.K - 4;
-            const float *p0 = A.in0 + (long)kc * A.Ppad + pg;
+            const float *u0 = tl_urow<BF>(A.in0, A, kt, g, bbase);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r0[4 * g + j] = p0[(long)j * A.Ppad];
+            for (int j = 0; j < 4; ++j) r0[4 * g + j] = tl_ldu(u0 + (long)j * A.Ppad, voffb);
             if (MODE == LD_BNBWD) {
-                const float *p1 = A.in1 + (long)kc * A.Ppad + pg;
+                const float *u1 = tl_urow<BF>(A.in1, A, kt, g, bbase);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r1[4 * g + j] = p1[(long)j * A.Ppad];
+                for (int j = 0; j < 4; ++j) r1[4 * g + j] = tl_ldu(u1 + (long)j * A.Ppad, voffb);
             }
         } else {
 #pragma unroll
@@ -173,15 +198,16 @@ __device__ __forceinline__ f32x16 tl_transform(const LayerArgs &A, int kt, bool 
 
 // dz of k-tile kt back over da (same rows, this lane's column): every element was read by this lane only
 template <bool k4, bool BF>
-__device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg, int h, const f32x16 &v) {
+__device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg, int h, const f32x16 &v, long bbase, unsigned voffb) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int k0 = tl_k0<BF>(kt, g, h);
         if (k4) {
-            if (k0 < A.K) {
-                float *d = A.dz_out + (long)k0 * A.Ppad + pg;
+            const int ku = tl_k0<BF>(kt, g, 0);
+            if (ku < A.K) {   // wave-uniform: the extent is a multiple of both lane halves' rows
+                float *d = A.dz_out + (long)ku * A.Ppad + bbase;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[(long)j * A.Ppad] = v[4 * g + j];
+                for (int j = 0; j < 4; ++j) tl_stu(d + (long)j * A.Ppad, voffb, v[4 * g + j]);
             }
         } else {
 #pragma unroll
@@ -195,8 +221,9 @@ __device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg,
 // by k-tile: while the CT*16 MFMAs of tile kt execute, the operands of tile kt+1 are already
 // in flight (fetched raw, transformed after the MFMAs), and the weights of the next chunk land
 // in the other LDS buffer by LDS-DMA (chunk = 32 fragments = 8/CT k-tiles).
-// K4: the reduction length is a multiple of four (every layer of the model; only first layers of hierarchical levels
-// are not), so the row bound is tested per group of four rows.
+// K4: the reduction length is a multiple of eight (of sixteen in bf16 mode) -- every layer of the model; only first
+// layers of hierarchical levels are not -- so the row bound is wave-uniform per group of rows and channel-major
+// addresses are scalar bases plus one lane offset (tl_urow).
 template <int MODE, int CT, bool OUT_PM, bool K4, bool BF = false>
 __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerArgs A) {
     // Up to 128 output rows (64 accumulator registers): three workgroups per CU -- 16-KiB weight chunks keep the LDS of
@@ -209,7 +236,10 @@ __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerA
     constexpr int KPC = CHF / FPK;   // k-tiles per weight chunk
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int p = lane & 31, h = lane >> 5;
-    const long pg = ((long)blockIdx.x * 4 + wave) * 32 + p;
+    const long bbase = (long)blockIdx.x * 128;   // the workgroup's first column
+    const long pg = bbase + wave * 32 + p;
+    const unsigned voffb = ((BF ? 8u : 4u) * (unsigned)h * (unsigned)A.Ppad + (unsigned)(wave * 32 + p)) * 4u;   // K4 addressing: see tl_urow
+    const unsigned voffo = (4u * (unsigned)h * (unsigned)A.Ppad + (unsigned)(wave * 32 + p)) * 4u;             // the same for output rows (8g + 4h + j)
     const bool valid = pg < A.P;
     const int KT = A.KT, KP = KT * 32;
     tl_stage<CHF>(A.wimg, wbuf, 0, wave, lane);   // first weight chunk flies while the operands load
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerA
         }
     }
     f32x16 r0, r1;
-    tl_fetch<MODE, K4, BF>(A, 0, pg, valid, h, r0, r1);
+    tl_fetch<MODE, K4, BF>(A, 0, pg, valid, h, r0, r1, bbase, voffb);
     f32x16 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -231,14 +261,14 @@ __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerA
         for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
     p2n_dma_barrier();   // tab visible (and chunk 0 landed)
     f32x16 cur = tl_transform<MODE, BF>(A, 0, valid, h, tab, KP, r0, r1);
-    if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4, BF>(A, 0, pg, h, cur);
+    if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4, BF>(A, 0, pg, h, cur, bbase, voffb);
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         if (kt % KPC == 0) {
             if (kt) p2n_dma_barrier();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
             if ((kt / KPC + 1) * KPC < KT) tl_stage<CHF>(A.wimg, wbuf, kt / KPC + 1, wave, lane);   // never a chunk nobody reads: nothing is pending when the workgroup ends
         }
-        if (kt + 1 < KT) tl_fetch<MODE, K4, BF>(A, kt + 1, pg, valid, h, r0, r1);   // queued behind the DMA, consumed after the MFMAs
+        if (kt + 1 < KT) tl_fetch<MODE, K4, BF>(A, kt + 1, pg, valid, h, r0, r1, bbase, voffb);   // queued behind the DMA, consumed after the MFMAs
         const float *wb = wbuf + ((kt / KPC) & 1) * (CHF * 256) + (kt % KPC) * (FPK * 256) + lane * 4;
         if (BF) {
 #pragma unroll
@@ -277,7 +307,7 @@ __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerA
         }
         if (kt + 1 < KT) {
             cur = tl_transform<MODE, BF>(A, kt + 1, valid, h, tab, KP, r0, r1);
-            if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4, BF>(A, kt + 1, pg, h, cur);
+            if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4, BF>(A, kt + 1, pg, h, cur, bbase, voffb);
         }
     }
     const int cloud = valid ? (int)(pg / A.N) : 0;
@@ -308,9 +338,15 @@ __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerA
                 if (OUT_PM) {
                     if (valid) *reinterpret_cast<f32x4 *>(A.out + pg * A.ld + r0i) = o;
                 } else {
-                    float *dst = A.out + (long)r0i * A.Ppad + pg;   // pad columns too (finite)
+                    if (K4) {
+                        float *dst = A.out + (long)(32 * ct + 8 * g) * A.Ppad + bbase;   // wave-uniform; pad columns too (finite)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dst[(long)j * A.Ppad] = o[j];
+                        for (int j = 0; j < 4; ++j) tl_stu(dst + (long)j * A.Ppad, voffo, o[j]);
+                    } else {
+                        float *dst = A.out + (long)r0i * A.Ppad + pg;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dst[(long)j * A.Ppad] = o[j];
+                    }
                 }
             }
         }
@@ -922,7 +958,7 @@ int launch_layer_p(LayerArgs a, hipStream_t s) {
     const dim3 grid(a.Ppad / 128), blk(256);
     a.KT = (a.K + 31) / 32;
     const int ps = p2n_prof_begin(P2N_K_TRAIN_GEMM, s);
-    if (a.K % 4 == 0) {
+    if (a.K % (BF ? 16 : 8) == 0 && a.Ppad < (1 << 26)) {   // scalar row bases + one 32-bit lane offset (tl_urow)
         switch (ct_pad(a.rows)) {
             case 1: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 1, PM, true, BF>), grid, blk, 0, s, a); break;
             case 2: hipLaunchKernelGGL((p2n_train_layer_kernel<MODE, 2, PM, true, BF>), grid, blk, 0, s, a); break;
