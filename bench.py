@@ -239,12 +239,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # P2N_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- the N>1 control flow (rendezvous, barriers, MAX over ranks,
+    # rank-0 line) on a one-GPU box; its number is NOT a scaling measurement and the line says so in `config`.
+    rehearse = world > 1 and os.environ.get("P2N_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from pointcloudsegmentation_amd import _lib
     from pointcloudsegmentation_amd.synth import make_batch
@@ -309,7 +316,8 @@ def main():
             "config": {"workload": "Point2Net eval forward, B=16 x N=8192 ScanNet-shaped clouds per GPU "
                                    "(BASELINE.json configs[1]), trained weights, scene-sharded, no collective",
                        "global_batch": world * B_PER_GPU, "points_per_cloud": N_POINTS, "parallelism": f"scenes x{world}",
-                       "prewarm_steps": PREWARM_STEPS},
+                       "prewarm_steps": PREWARM_STEPS,
+                       **({"rehearsal": "all ranks on cuda:0 over gloo: control flow only, not a scaling figure"} if rehearse else {})},
             "per_gpu_value": value / world,
             "step_tflops_algorithmic": FLOP_PER_PT_STEP * pts_step / (elapsed / args.steps) / 1e12,
             "kernels_ms": {k: v[0] for k, v in kernels.items() if v[1]},
