@@ -55,6 +55,8 @@ def _compare_modules(gpu, ref, what, grad_bar=5e-4):
     (259, [100, 33], True, 1, 515, True),            # channel counts that fill no tile
     (131, [128], False, 2, 300, True),               # one layer
     (40, [7], True, 2, 300, True),                   # one plain layer
+    (8, [24, 40, 72], False, 2, 300, True),          # reduction lengths 8, 24, 40: multiples of 8 with a ragged last k-tile (scalar-base addressing, clamped rows)
+    (12, [20, 44, 16], True, 2, 515, True),          # reduction lengths 12, 20, 44: multiples of 4 only (general addressing path)
 ])
 def test_shared_mlp_train_matches_float64_torch(cin, chans, last_plain, B, L, need_dx):
     from pointcloudsegmentation_amd.pointnet2 import SharedMLP
