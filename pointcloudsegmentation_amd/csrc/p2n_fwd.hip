@@ -115,12 +115,17 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 // This wave's quarter (8 fragments) of chunk c of a weight stream -> LDS buffer c&1.
 // LDS-DMA: the destination is wave-uniform base + lane*16, i.e. the lane-linear fragment image.
+// As a buffer instruction: the stream base sits in a scalar resource, the fragment's offset is scalar arithmetic and the
+// lane offset one constant register, so staging costs no vector-ALU instruction (whose time adds to the MFMAs':
+// DESIGN section 7; written as a pointer it cost one 64-bit vector add and a readfirstlane per fragment).
 __device__ __forceinline__ void stage_chunk(const float *__restrict__ stream, float *wbuf, int c, int wave, int lane) {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(stream), 0, -1, 0x00020000);
 #pragma unroll
     for (int i = 0; i < P2N_CHUNK / P2N_WAVES_PER_WG; ++i) {
-        const int f = wave * (P2N_CHUNK / P2N_WAVES_PER_WG) + i;
-        __builtin_amdgcn_global_load_lds((gbl_void *)(stream + ((long)c * P2N_CHUNK + f) * P2N_FRAG_FLOATS + lane * 4),
-                                         (lds_void *)(wbuf + (c & 1) * CHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16, 0, 0);
+        const int f = wv * (P2N_CHUNK / P2N_WAVES_PER_WG) + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(wbuf + (c & 1) * CHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16,
+                                                 lane * 16, (c * P2N_CHUNK + f) * (P2N_FRAG_FLOATS * 4), 0, 0);
     }
 }
 
