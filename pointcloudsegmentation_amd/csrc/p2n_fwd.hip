@@ -103,7 +103,14 @@ __global__ void p2n_pack_kernel(const float *__restrict__ raw, float *__restrict
         if (l >= 0) {
             int co = 32 * ct + row, k = 8 * G + 4 * h + j;
             int klim = (l == 6) ? 256 : L.cin[l];
-            if (co < L.cout[l] && k < klim) v = raw[L.raw_w[l] + (long)co * L.cin[l] + k];
+            if (co < L.cout[l] && k < klim) {
+                // BatchNorm's scale is folded into the weight (product in double, one rounding): the kernels start
+                // their accumulators at the shift and the epilogue is the ReLU alone -- one vector-ALU instruction
+                // per output element instead of two, and vector-ALU time adds to MFMA time
+                double w = raw[L.raw_w[l] + (long)co * L.cin[l] + k];
+                if (l < 8) w *= (double)raw[L.raw_g[l] + co] / sqrt((double)raw[L.raw_var[l] + co] + 1e-5);
+                v = (float)w;
+            }
         }
     }
     packed[i] = v;
@@ -144,21 +151,27 @@ __device__ __forceinline__ f32x4 lds_frag(const float *wbuf, int f, int lane) {
                                             (f % P2N_CHUNK) * P2N_FRAG_FLOATS + lane * 4);
 }
 
-// y = relu(acc*scale + shift) on one 32x32 accumulator tile; channel of register
-// 4g+j in lane half h is 32*ct + 8g + 4h + j.
-template <bool RELU>
-__device__ __forceinline__ f32x16 epilogue(const f32x16 acc, const float *scale, const float *shift, int ct, int h) {
+// The layer's shift (BatchNorm shift with the conv bias folded in, or the per-cloud layer-6 shift) is where the
+// accumulators START; the scale sits in the packed weights.  Channel of register 4g+j in lane half h: 32*ct + 8g + 4h + j.
+__device__ __forceinline__ f32x16 shift_tile(const float *shift, int ct, int h) {
     f32x16 out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 32 * ct + 8 * g + 4 * h);
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 32 * ct + 8 * g + 4 * h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = fmaf(acc[4 * g + j], sc[j], sh[j]);
-            out[4 * g + j] = RELU ? fmaxf(v, 0.f) : v;
-        }
+        for (int j = 0; j < 4; ++j) out[4 * g + j] = sh[j];
     }
+    return out;
+}
+template <int CT>
+__device__ __forceinline__ void shift_tiles(f32x16 (&t)[CT], const float *shift, int h) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) t[c] = shift_tile(shift, c, h);
+}
+__device__ __forceinline__ f32x16 relu_tile(const f32x16 acc) {
+    f32x16 out;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = fmaxf(acc[i], 0.f);
     return out;
 }
 
@@ -166,7 +179,7 @@ __device__ __forceinline__ f32x16 epilogue(const f32x16 acc, const float *scale,
 // take turns on the matrix pipe (no MFMA ever waits on its predecessor) and every epilogue
 // of the layer happens once, after the last k-tile.  Consumes KT*CT*4 consecutive weight
 // fragments, ordered [kt][ct][g], starting at stream index F0 (compile-time, so LDS
-// offsets are immediates).  acc must come in zeroed.
+// offsets are immediates).  acc comes in holding the layer's shift (shift_tiles).
 template <int KT, int CT, int F0>
 __device__ __forceinline__ void layer_kt_outer(const float *__restrict__ stream, float *wbuf, int wave, int lane,
                                                const f32x16 (&in)[KT], f32x16 (&acc)[CT]) {
@@ -248,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
     for (int i = threadIdx.x; i < A.tab_n; i += 256) tab[i] = pk[A.tab + i];
     smax[threadIdx.x] = 0u;
     const bool valid = n < A.N;
+    const bool wave_full = n - p + P2N_PTS_PER_WAVE <= A.N;   // the wave's 32 points all lie inside the cloud
     const long grp = (long)blockIdx.x * P2N_WAVES_PER_WG + wave;
 
     // layer 0 operand: x[n][4h+j], zero beyond F (K padded to 8) and beyond the cloud
@@ -261,42 +275,40 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
     f32x16 a0[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         chunk_gate(ct, stream, wbuf, wave, lane);   // ct == 0: first barrier (chunk 0, tables, smax)
+        f32x16 acc = shift_tile(tab + A.shift[0], ct, h);
         const f32x4 a = lds_frag(wbuf, ct, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], xin[j], acc);
-        a0[ct] = epilogue<true>(acc, tab + A.scale[0], tab + A.shift[0], ct, h);
+        a0[ct] = relu_tile(acc);
     }
     // stream positions: L0 2 frags, L1 16, L2 32, L3 64, L4 128, L5 4 x 64
     f32x16 a1[2];
-    zero_tiles(a1);
+    shift_tiles(a1, tab + A.shift[1], h);
     layer_kt_outer<2, 2, 2>(stream, wbuf, wave, lane, a0, a1);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        a1[ct] = epilogue<true>(a1[ct], tab + A.scale[1], tab + A.shift[1], ct, h);
+        a1[ct] = relu_tile(a1[ct]);
         if (FEATS) if (A.f1) store_feat<64>(A.f1, a1[ct], b, ct, h, n, A.N);
     }
     f32x16 a2[4];
-    zero_tiles(a2);
+    shift_tiles(a2, tab + A.shift[2], h);
     layer_kt_outer<2, 4, 18>(stream, wbuf, wave, lane, a1, a2);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) a2[ct] = epilogue<true>(a2[ct], tab + A.scale[2], tab + A.shift[2], ct, h);
+    for (int ct = 0; ct < 4; ++ct) a2[ct] = relu_tile(a2[ct]);
     f32x16 a3[4];
-    zero_tiles(a3);
+    shift_tiles(a3, tab + A.shift[3], h);
     layer_kt_outer<4, 4, 50>(stream, wbuf, wave, lane, a2, a3);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-        a3[ct] = epilogue<true>(a3[ct], tab + A.scale[3], tab + A.shift[3], ct, h);
+        a3[ct] = relu_tile(a3[ct]);
         if (FEATS) if (A.f2) store_feat<128>(A.f2, a3[ct], b, ct, h, n, A.N);
     }
     f32x16 a4[8];
-    zero_tiles(a4);
+    shift_tiles(a4, tab + A.shift[4], h);
     layer_kt_outer<4, 8, 114>(stream, wbuf, wave, lane, a3, a4);
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) a4[ct] = epilogue<true>(a4[ct], tab + A.scale[4], tab + A.shift[4], ct, h);
+    for (int ct = 0; ct < 8; ++ct) a4[ct] = relu_tile(a4[ct]);
     // layer 5 in four passes of two output tiles: with its 128 input registers live, two
     // independent accumulators (32 registers) leave room for the epilogue without spilling;
     // results leave through the spill and the channel max
@@ -304,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x16 a5[2];
-        zero_tiles(a5);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) a5[c2] = shift_tile(tab + A.shift[5], 2 * q + c2, h);
         if (q == 0) layer_kt_outer<8, 2, 242>(stream, wbuf, wave, lane, a4, a5);
         else if (q == 1) layer_kt_outer<8, 2, 306>(stream, wbuf, wave, lane, a4, a5);
         else if (q == 2) layer_kt_outer<8, 2, 370>(stream, wbuf, wave, lane, a4, a5);
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             const int ct = 2 * q + c2;
-            const f32x16 v = epilogue<true>(a5[c2], tab + A.scale[5], tab + A.shift[5], ct, h);
+            const f32x16 v = relu_tile(a5[c2]);
             if (FEATS) if (A.f3) store_feat<256>(A.f3, v, b, ct, h, n, A.N);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -323,9 +336,11 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
             // integers and 0 is the neutral element for masked points.  Halving transpose-reduce over the 32 lanes
             // of each wave half (15 DPP maxima + one swizzle per tile, p2n_common.h; 16 x four DPP steps before),
             // after which lane i of a row holds the maximum of register i: one LDS atomic per tile.
-            f32x16 vm;
+            f32x16 vm = v;
+            if (!wave_full) {   // wave-uniform: only a cloud's last wave has points past its end
 #pragma unroll
-            for (int i = 0; i < 16; ++i) vm[i] = valid ? v[i] : 0.f;
+                for (int i = 0; i < 16; ++i) vm[i] = valid ? v[i] : 0.f;
+            }
             const int mx = __float_as_int(p2n_tile_half_max(vm, lane));
             if ((lane & 16) == 0)
                 atomicMax(&smax[32 * ct + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3)], (unsigned)(mx > 0 ? mx : 0));   // (-0.0 -> 0)
@@ -410,11 +425,9 @@ __global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
     // prefetched), used by all eight output tiles, dropped.  Chunk kt of the stream holds
     // exactly the 32 fragments of k-slice kt.
     const f32x4 *sp = reinterpret_cast<const f32x4 *>(A.spill + grp * (256L * P2N_PTS_PER_WAVE)) + lane;
+    __syncthreads();   // tables and this cloud's layer-6 shift are in LDS: the accumulators start from them
     f32x16 acc6[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc6[c][i] = 0.f;
+    shift_tiles(acc6, sh6, h);
     f32x4 cur[4], nxt[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) cur[g] = sp[g * P2N_WAVE];
@@ -439,14 +452,11 @@ __global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
     }
     f32x16 a6[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) a6[c] = epilogue<true>(acc6[c], tab + A.scale6, sh6, c, h);
+    for (int c = 0; c < 8; ++c) a6[c] = relu_tile(acc6[c]);
 
     // ---- layer 7, k-tile outer as well: a6[kt] dies as soon as its slice is consumed
     f32x16 a7[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a7[c][i] = 0.f;
+    shift_tiles(a7, tab + A.shift7, h);
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
                 for (int j = 0; j < 4; ++j) a7[ct] = MFMA32(a[j], a6[kt][4 * g + j], a7[ct]);
             }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a7[c] = epilogue<true>(a7[c], tab + A.scale7, tab + A.shift7, c, h);
+    for (int c = 0; c < 4; ++c) a7[c] = relu_tile(a7[c]);
 
     // ---- layer 8: runtime number of 32-channel tiles, two per chunk (16 fragments each).
     // Output: lane (p,h) holds 4 consecutive channels per register group, so every point's
@@ -481,9 +491,7 @@ __global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
         for (int half = 0; half < 2; ++half) {
             const int ct8 = 2 * c8 + half;
             if (ct8 < A.ct8) {
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                f32x16 acc = shift_tile(tab + A.shift8, ct8, h);   // the plain last layer: its bias
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void p2n_head_kernel(HeadArgs A) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], a7[kt][4 * g + j], acc);
                     }
-                const f32x16 v = epilogue<false>(acc, tab + A.scale8, tab + A.shift8, ct8, h);
+                const f32x16 v = acc;
                 if (valid) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
