@@ -212,11 +212,15 @@ struct WStream {
         // opaque chunk number: otherwise the 8 x NCHUNK global addresses of a stream are hoisted out of the
         // block loop as loop invariants and spill
         asm volatile("" : "+s"(c));
+        // buffer LDS-DMA: stream offset on the scalar unit, one constant lane offset -- no vector-ALU address
+        // arithmetic, whose time would add to the MFMAs' 
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(stream), 0, -1, 0x00020000);
 #pragma unroll
         for (int i = 0; i < P2N_CHUNK / P2N_WAVES_PER_WG; ++i) {
-            const int f = wave * (P2N_CHUNK / P2N_WAVES_PER_WG) + i;
-            __builtin_amdgcn_global_load_lds((gbl_void *)(stream + ((long)c * P2N_CHUNK + f) * P2N_FRAG_FLOATS + lane * 4),
-                                             (lds_void *)(wbuf + (c & 1) * CHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16, 0, 0);
+            const int f = wv * (P2N_CHUNK / P2N_WAVES_PER_WG) + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(wbuf + (c & 1) * CHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16,
+                                                     lane * 16, (c * P2N_CHUNK + f) * (P2N_FRAG_FLOATS * 4), 0, 0);
         }
     }
     __device__ __forceinline__ void load_resident(int nfrag) const {
