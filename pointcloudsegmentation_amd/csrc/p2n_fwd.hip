@@ -171,7 +171,13 @@ __device__ __forceinline__ void shift_tiles(f32x16 (&t)[CT], const float *shift,
 __device__ __forceinline__ f32x16 relu_tile(const f32x16 acc) {
     f32x16 out;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) out[i] = fmaxf(acc[i], 0.f);
+    // ReLU on the bit pattern: positive floats are positive integers, negative ones (and -0) negative, so
+    // max_i32(bits, 0) is relu(x) in ONE instruction.  fmaxf(x, 0) on an MFMA result costs two: the compiler first
+    // canonicalises a value it cannot prove quiet (v_max x, x) -- the fused multiply-add used to do that on the side.
+    for (int i = 0; i < 16; ++i) {
+        const int b = __float_as_int(acc[i]);
+        out[i] = __int_as_float(b > 0 ? b : 0);
+    }
     return out;
 }
 
