@@ -143,11 +143,14 @@ typedef const __attribute__((address_space(1))) void gbl_void_b;
 #define DMA_PER_WAVE (P2N_CHUNK / NWB)
 
 __device__ __forceinline__ void stage_chunk_b(const float *__restrict__ stream, float *wbuf, int c, int wave, int lane) {
+    // buffer LDS-DMA: stream offset on the scalar unit, one constant lane offset (no vector-ALU address arithmetic)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(stream), 0, -1, 0x00020000);
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) {
-        const int f = wave * DMA_PER_WAVE + i;
-        __builtin_amdgcn_global_load_lds((gbl_void_b *)(stream + ((long)c * P2N_CHUNK + f) * P2N_FRAG_FLOATS + lane * 4),
-                                         (lds_void_b *)(wbuf + (c % RING) * BCHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16, 0, 0);
+        const int f = wv * DMA_PER_WAVE + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_b *)(wbuf + (c % RING) * BCHUNK_FLOATS + f * P2N_FRAG_FLOATS), 16,
+                                                 lane * 16, (c * P2N_CHUNK + f) * (P2N_FRAG_FLOATS * 4), 0, 0);
     }
 }
 
