@@ -121,7 +121,13 @@ __global__ void p2n_pack_bf16_kernel(const float *__restrict__ raw, float *__res
                 const int co = 32 * ct + row;
                 const int klim = (l == 6) ? 256 : L.cin[l];
                 float w = 0.f;
-                if (co < L.cout[l] && k < klim) w = raw[L.raw_w[l] + (long)co * L.cin[l] + k];
+                if (co < L.cout[l] && k < klim) {
+                    // BatchNorm's scale folded into the weight (in double, before the bf16 rounding / hi-lo split): the
+                    // accumulators start at the shift and the epilogue is the ReLU alone (see p2n_fwd.hip)
+                    double wd = raw[L.raw_w[l] + (long)co * L.cin[l] + k];
+                    if (l < 8) wd *= (double)raw[L.raw_g[l] + co] / sqrt((double)raw[L.raw_var[l] + co] + 1e-5);
+                    w = (float)wd;
+                }
                 const float hi = bf16_round(w);
                 bits[q] = bf16_bits(lo ? w - hi : w);
             }
@@ -178,18 +184,24 @@ __device__ __forceinline__ bf16x8 frag_b(const float *wbuf, int f, int lane) {
                                              lane * 4);
 }
 
-template <bool RELU>
-__device__ __forceinline__ f32x16 epilogue_b(const f32x16 acc, const float *scale, const float *shift, int ct, int h) {
+// a layer's accumulators start at its shift (channel of register 4g+j in lane half h: 32ct + 8g + 4h + j) ...
+__device__ __forceinline__ f32x16 shift_tile_b(const float *shift, int ct, int h) {
     f32x16 out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 32 * ct + 8 * g + 4 * h);
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 32 * ct + 8 * g + 4 * h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = fmaf(acc[4 * g + j], sc[j], sh[j]);
-            out[4 * g + j] = RELU ? fmaxf(v, 0.f) : v;
-        }
+        for (int j = 0; j < 4; ++j) out[4 * g + j] = sh[j];
+    }
+    return out;
+}
+// ... and the epilogue is the ReLU alone, as one integer max on the bit pattern (p2n_fwd.hip: relu_tile)
+__device__ __forceinline__ f32x16 relu_tile_b(const f32x16 acc) {
+    f32x16 out;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int b = __float_as_int(acc[i]);
+        out[i] = __int_as_float(b > 0 ? b : 0);
     }
     return out;
 }
@@ -218,13 +230,14 @@ __device__ __forceinline__ f32x16 zero16() {
 
 // one output tile of a plain bf16 layer: KS k-steps, fragments F0 .. F0+KS-1
 template <int KS, int F0>
-__device__ __forceinline__ f32x16 tile_plain(const float *stream, float *wbuf, int wave, int lane, const bf16x8 (&in)[KS]) {
+__device__ __forceinline__ f32x16 tile_plain(const float *stream, float *wbuf, int wave, int lane, const bf16x8 (&in)[KS],
+                                             const float *shift, int ct, int h) {
     // all KS fragments of the tile are fetched before its MFMAs start (a chunk boundary may fall inside:
     // the fetch stops there, crosses the gate, and goes on)
-    f32x16 acc = zero16();
     bf16x8 w[KS];
     constexpr int SPLIT = ((F0 / P2N_CHUNK) != ((F0 + KS - 1) / P2N_CHUNK)) ? ((F0 / P2N_CHUNK + 1) * P2N_CHUNK - F0) : KS;
     if (F0 % P2N_CHUNK == 0) gate_b(F0, stream, wbuf, wave, lane);
+    f32x16 acc = shift_tile_b(shift, ct, h);   // behind the gate: the kernel's first gate is what makes the tables visible
 #pragma unroll
     for (int ks = 0; ks < SPLIT; ++ks) w[ks] = frag_b(wbuf, F0 + ks, lane);
 #pragma unroll
@@ -242,11 +255,12 @@ __device__ __forceinline__ f32x16 tile_plain(const float *stream, float *wbuf, i
 // one output tile of a split layer: fragments F0 + 2ks (weights hi), F0 + 2ks + 1 (weights lo)
 template <int KS, int F0>
 __device__ __forceinline__ f32x16 tile_split(const float *stream, float *wbuf, int wave, int lane, const bf16x8 (&hi)[KS],
-                                             const bf16x8 (&lo)[KS]) {
-    f32x16 acc = zero16();
+                                             const bf16x8 (&lo)[KS], const float *shift, int ct, int h) {
+    f32x16 acc;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         gate_b(F0 + 2 * ks, stream, wbuf, wave, lane);
+        if (ks == 0) acc = shift_tile_b(shift, ct, h);   // behind the first gate (tables visible)
         const bf16x8 wh = frag_b(wbuf, F0 + 2 * ks, lane);
         gate_b(F0 + 2 * ks + 1, stream, wbuf, wave, lane);
         const bf16x8 wl = frag_b(wbuf, F0 + 2 * ks + 1, lane);
@@ -291,7 +305,7 @@ __device__ __forceinline__ void halve_max(unsigned (&m)[16], bool upper) {
 __device__ __forceinline__ unsigned tile_rowmax(const f32x16 v, bool valid, int lane) {
     unsigned m[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) m[i] = valid ? __float_as_uint(v[i]) : 0u;
+    for (int i = 0; i < 16; ++i) m[i] = valid ? __float_as_uint(v[i]) : 0u;   // (valid is wave-uniformly true except in a cloud's last wave)
     halve_max<8, 0xB1>(m, lane & 1);    // quad_perm [1,0,3,2]
     halve_max<4, 0x4E>(m, lane & 2);    // quad_perm [2,3,0,1]
     halve_max<2, 0x124>(m, lane & 4);   // row_ror:4
@@ -356,16 +370,18 @@ __global__ __launch_bounds__(NWB * 64, 2) void p2n_encoder_bf16_kernel(EncArgsB 
     bf16x8 a0h[4], a0l[4];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        f32x16 acc = ct == 0 ? tile_split<1, 0>(stream, wbuf, wave, lane, x_hi, x_lo) : tile_split<1, 2>(stream, wbuf, wave, lane, x_hi, x_lo);
-        const f32x16 v = epilogue_b<true>(acc, tab + A.scale[0], tab + A.shift[0], ct, h);
+        f32x16 acc = ct == 0 ? tile_split<1, 0>(stream, wbuf, wave, lane, x_hi, x_lo, tab + A.shift[0], ct, h)
+                             : tile_split<1, 2>(stream, wbuf, wave, lane, x_hi, x_lo, tab + A.shift[0], ct, h);
+        const f32x16 v = relu_tile_b(acc);
         pack_tile_split(v, a0h[2 * ct], a0h[2 * ct + 1], a0l[2 * ct], a0l[2 * ct + 1]);
     }
     // ---- layer 1: 64 -> 64 (split)           fragments 4..19
     bf16x8 a1h[4], a1l[4];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        f32x16 acc = ct == 0 ? tile_split<4, 4>(stream, wbuf, wave, lane, a0h, a0l) : tile_split<4, 12>(stream, wbuf, wave, lane, a0h, a0l);
-        const f32x16 v = epilogue_b<true>(acc, tab + A.scale[1], tab + A.shift[1], ct, h);
+        f32x16 acc = ct == 0 ? tile_split<4, 4>(stream, wbuf, wave, lane, a0h, a0l, tab + A.shift[1], ct, h)
+                             : tile_split<4, 12>(stream, wbuf, wave, lane, a0h, a0l, tab + A.shift[1], ct, h);
+        const f32x16 v = relu_tile_b(acc);
         if (FEATS) if (A.f1) store_feat_b<64>(A.f1, v, b, ct, h, n, A.N);
         pack_tile_split(v, a1h[2 * ct], a1h[2 * ct + 1], a1l[2 * ct], a1l[2 * ct + 1]);
     }
@@ -374,11 +390,11 @@ __global__ __launch_bounds__(NWB * 64, 2) void p2n_encoder_bf16_kernel(EncArgsB 
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         f32x16 acc;
-        if (ct == 0) acc = tile_split<4, 20>(stream, wbuf, wave, lane, a1h, a1l);
-        else if (ct == 1) acc = tile_split<4, 28>(stream, wbuf, wave, lane, a1h, a1l);
-        else if (ct == 2) acc = tile_split<4, 36>(stream, wbuf, wave, lane, a1h, a1l);
-        else acc = tile_split<4, 44>(stream, wbuf, wave, lane, a1h, a1l);
-        const f32x16 v = epilogue_b<true>(acc, tab + A.scale[2], tab + A.shift[2], ct, h);
+        if (ct == 0) acc = tile_split<4, 20>(stream, wbuf, wave, lane, a1h, a1l, tab + A.shift[2], ct, h);
+        else if (ct == 1) acc = tile_split<4, 28>(stream, wbuf, wave, lane, a1h, a1l, tab + A.shift[2], ct, h);
+        else if (ct == 2) acc = tile_split<4, 36>(stream, wbuf, wave, lane, a1h, a1l, tab + A.shift[2], ct, h);
+        else acc = tile_split<4, 44>(stream, wbuf, wave, lane, a1h, a1l, tab + A.shift[2], ct, h);
+        const f32x16 v = relu_tile_b(acc);
         pack_tile(v, a2[2 * ct], a2[2 * ct + 1]);
     }
     // ---- layer 3: 128 -> 128                 fragments 52..83
@@ -386,26 +402,26 @@ __global__ __launch_bounds__(NWB * 64, 2) void p2n_encoder_bf16_kernel(EncArgsB 
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         f32x16 acc;
-        if (ct == 0) acc = tile_plain<8, 52>(stream, wbuf, wave, lane, a2);
-        else if (ct == 1) acc = tile_plain<8, 60>(stream, wbuf, wave, lane, a2);
-        else if (ct == 2) acc = tile_plain<8, 68>(stream, wbuf, wave, lane, a2);
-        else acc = tile_plain<8, 76>(stream, wbuf, wave, lane, a2);
-        const f32x16 v = epilogue_b<true>(acc, tab + A.scale[3], tab + A.shift[3], ct, h);
+        if (ct == 0) acc = tile_plain<8, 52>(stream, wbuf, wave, lane, a2, tab + A.shift[3], ct, h);
+        else if (ct == 1) acc = tile_plain<8, 60>(stream, wbuf, wave, lane, a2, tab + A.shift[3], ct, h);
+        else if (ct == 2) acc = tile_plain<8, 68>(stream, wbuf, wave, lane, a2, tab + A.shift[3], ct, h);
+        else acc = tile_plain<8, 76>(stream, wbuf, wave, lane, a2, tab + A.shift[3], ct, h);
+        const f32x16 v = relu_tile_b(acc);
         if (FEATS) if (A.f2) store_feat_b<128>(A.f2, v, b, ct, h, n, A.N);
         pack_tile(v, a3[2 * ct], a3[2 * ct + 1]);
     }
     // ---- layer 4: 128 -> 256                 fragments 84..147
     bf16x8 a4[16];
-#define P2N_L4(ct) { const f32x16 acc = tile_plain<8, 84 + 8 * (ct)>(stream, wbuf, wave, lane, a3);              \
-                     const f32x16 v = epilogue_b<true>(acc, tab + A.scale[4], tab + A.shift[4], (ct), h);          \
+#define P2N_L4(ct) { const f32x16 acc = tile_plain<8, 84 + 8 * (ct)>(stream, wbuf, wave, lane, a3, tab + A.shift[4], (ct), h);              \
+                     const f32x16 v = relu_tile_b(acc);          \
                      pack_tile(v, a4[2 * (ct)], a4[2 * (ct) + 1]); }
     P2N_L4(0) P2N_L4(1) P2N_L4(2) P2N_L4(3) P2N_L4(4) P2N_L4(5) P2N_L4(6) P2N_L4(7)
 #undef P2N_L4
     // ---- layer 5: 256 -> 256                 fragments 148..275; results leave through the spill and the max
     char *sp = reinterpret_cast<char *>(A.spill) + grp * (16L * 1024) + lane * 16;
     unsigned wm[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // this lane's row maxima, one per output tile
-#define P2N_L5(ct) { const f32x16 acc = tile_plain<16, 148 + 16 * (ct)>(stream, wbuf, wave, lane, a4);            \
-                     const f32x16 v = epilogue_b<true>(acc, tab + A.scale[5], tab + A.shift[5], (ct), h);          \
+#define P2N_L5(ct) { const f32x16 acc = tile_plain<16, 148 + 16 * (ct)>(stream, wbuf, wave, lane, a4, tab + A.shift[5], (ct), h);            \
+                     const f32x16 v = relu_tile_b(acc);          \
                      if (FEATS) if (A.f3) store_feat_b<256>(A.f3, v, b, (ct), h, n, A.N);                          \
                      bf16x8 s0, s1;                                                                                \
                      pack_tile(v, s0, s1);                                                                         \
@@ -485,15 +501,15 @@ __global__ __launch_bounds__(NWB * 64, 2) void p2n_head_bf16_kernel(HeadArgsB A)
 
     // ---- layer 6: 256 (+ folded global half) -> 256     fragments 0..127
     bf16x8 a6[16];
-#define P2N_L6(ct) { const f32x16 acc = tile_plain<16, 16 * (ct)>(stream, wbuf, wave, lane, f3);                 \
-                     const f32x16 v = epilogue_b<true>(acc, tab + A.scale6, sh6, (ct), h);                         \
+#define P2N_L6(ct) { const f32x16 acc = tile_plain<16, 16 * (ct)>(stream, wbuf, wave, lane, f3, sh6, (ct), h);                 \
+                     const f32x16 v = relu_tile_b(acc);                         \
                      pack_tile(v, a6[2 * (ct)], a6[2 * (ct) + 1]); }
     P2N_L6(0) P2N_L6(1) P2N_L6(2) P2N_L6(3) P2N_L6(4) P2N_L6(5) P2N_L6(6) P2N_L6(7)
 #undef P2N_L6
     // ---- layer 7: 256 -> 128                             fragments 128..191
     bf16x8 a7[8];
-#define P2N_L7(ct) { const f32x16 acc = tile_plain<16, 128 + 16 * (ct)>(stream, wbuf, wave, lane, a6);           \
-                     const f32x16 v = epilogue_b<true>(acc, tab + A.scale7, tab + A.shift7, (ct), h);              \
+#define P2N_L7(ct) { const f32x16 acc = tile_plain<16, 128 + 16 * (ct)>(stream, wbuf, wave, lane, a6, tab + A.shift7, (ct), h);           \
+                     const f32x16 v = relu_tile_b(acc);              \
                      pack_tile(v, a7[2 * (ct)], a7[2 * (ct) + 1]); }
     P2N_L7(0) P2N_L7(1) P2N_L7(2) P2N_L7(3)
 #undef P2N_L7
@@ -513,11 +529,11 @@ __global__ __launch_bounds__(NWB * 64, 2) void p2n_head_bf16_kernel(HeadArgsB A)
         for (int q = 0; q < 4; ++q) {
             const int ct8 = 4 * c8 + q;
             if (ct8 < A.ct8) {
-                f32x16 acc = zero16();
+                f32x16 acc = shift_tile_b(tab + A.shift8, ct8, h);   // the plain last layer: its bias
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
                     acc = MFMAB(*reinterpret_cast<const bf16x8 *>(wb + (q * 8 + ks) * P2N_FRAG_FLOATS), a7[ks], acc);
-                const f32x16 v = epilogue_b<false>(acc, tab + A.scale8, tab + A.shift8, ct8, h);
+                const f32x16 v = acc;
                 if (valid) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
