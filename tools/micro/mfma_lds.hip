@@ -13,9 +13,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LD 68
 
 // MODE 0: operands in registers; 1: A from LDS (row-strided), B registers; 2: A and B from LDS (row-strided, the kernel's
-// addressing); 3: A and B from LDS, lane-linear addresses (lane * 16 bytes: no bank conflict possible)
+// addressing); 3: A and B from LDS, lane-linear addresses (lane * 16 bytes: no bank conflict possible);
+// 4 / 5: as 2 with the kernel's park phase behind every step (see below)
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k(float *out, int steps) {
+__global__ __launch_bounds__(256, 2) void k(float *out, int steps, const float *src, int ld) {
     __shared__ __attribute__((aligned(16))) float sa[2 * 64 * LD], sb[2 * 64 * LD];
     for (int i = threadIdx.x; i < 2 * 64 * LD; i += 256) { sa[i] = 1e-3f * i; sb[i] = 1.f - 1e-3f * i; }
     __syncthreads();
@@ -47,6 +48,30 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int steps) {
                     for (int q = 0; q < 2; ++q) acc[i][q] = MFMA32(av[i][j], bv[q][j], acc[i][q]);
         }
         asm volatile("" ::: "memory");   // the LDS reads of every step are really issued
+        if (MODE >= 4) {
+            // the kernel's park phase: barrier, this thread's 4 x 16 floats of the next operand blocks (loaded from
+            // global memory: MODE 5; from registers: MODE 4) through BatchNorm+ReLU into LDS rows, barrier
+            __syncthreads();
+            const int t = threadIdx.x, row = t >> 2, seg = (t & 3) * 16;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                float *dst = (blk < 2 ? sa : sb) + (blk & 1) * 64 * LD + row * LD + seg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = ra[blk & 1];
+                    if (MODE == 5) v = *reinterpret_cast<const f32x4 *>(src + ((long)(blockIdx.x & 63) * 64 + row) * ld + ((s * 64 + seg + 4 * i) & (ld - 1)) + blk * 16);
+                    // MODE 6: the kernel's real operand layout -- 256 rows of 262,144 points (1-MiB row stride, 268 MB), this
+                    // workgroup's slice of 2,048 points, 64 points per step: 256 contiguous bytes per row per step
+                    if (MODE == 6) v = *reinterpret_cast<const f32x4 *>(src + ((long)(((blockIdx.x & 1) * 2 + (blk & 1)) * 64 + row)) * 262144 +
+                                                                        (long)(blockIdx.x >> 2) * 2048 + ((s & 31) * 64 + seg + 4 * i));
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(v[j], rb[0][j], rb[1][j]), 0.f);
+                    *reinterpret_cast<f32x4 *>(dst + 4 * i) = o;
+                }
+            }
+            __syncthreads();
+        }
     }
     float t = 0.f;
     for (int i = 0; i < 2; ++i)
@@ -56,14 +81,14 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int steps) {
 }
 
 template <int MODE>
-static int run(float *out, const char *name) {
+static int run(float *out, const float *src, const char *name) {
     const int steps = getenv("STEPS") ? atoi(getenv("STEPS")) : 256;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0.f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((k<MODE>), dim3(512), dim3(256), 0, 0, out, steps);
+        hipLaunchKernelGGL((k<MODE>), dim3(512), dim3(256), 0, 0, out, steps, src, 4096);
         CK(hipEventRecord(e1, 0));
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
@@ -77,9 +102,15 @@ static int run(float *out, const char *name) {
 int main() {
     float *out;
     CK(hipMalloc(&out, sizeof(float) * 512 * 256));
-    if (run<0>(out, "operands in registers")) return 1;
-    if (run<1>(out, "A fragments from LDS (row-strided), B in registers")) return 1;
-    if (run<2>(out, "A and B fragments from LDS (row-strided: the kernel's loop)")) return 1;
-    if (run<3>(out, "A and B fragments from LDS (lane-linear addresses)")) return 1;
+    float *src;
+    CK(hipMalloc(&src, sizeof(float) * 256 * 262144));
+    CK(hipMemset(src, 0, sizeof(float) * 256 * 262144));
+    if (run<0>(out, src, "operands in registers")) return 1;
+    if (run<1>(out, src, "A fragments from LDS (row-strided), B in registers")) return 1;
+    if (run<2>(out, src, "A and B fragments from LDS (row-strided: the kernel's loop)")) return 1;
+    if (run<3>(out, src, "A and B fragments from LDS (lane-linear addresses)")) return 1;
+    if (run<4>(out, src, "as 2, plus per step: barrier, transform + LDS stores, barrier")) return 1;
+    if (run<5>(out, src, "as 4, the parked data loaded from global memory (cache-resident)")) return 1;
+    if (run<6>(out, src, "as 4, loaded in the kernel's layout: 1-MiB row stride, 268 MB")) return 1;
     return 0;
 }
