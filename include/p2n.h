@@ -70,7 +70,11 @@ int p2n_forward_eval(const float *x, int B, int N, int feature_dim, int embeddin
  * a device array built into the library (34 MB per GPU, held until the process ends), so the call is
  * limited to B*ceil(N/128) <= P2N_NOALLOC_MAX_TILES workgroups (32,768 points when N is a multiple of
  * 128) and returns P2N_EINVAL beyond.  The call allocates nothing (no hipMalloc/hipFree).  All calls on one
- * GPU share that array: calls that overlap on one GPU (two streams, two threads) race. */
+ * GPU share that array: calls that overlap on one GPU (two streams, two threads) race.
+ * The array is part of the library's code object: EVERY GPU of EVERY process that loads libp2n_hip.so holds its
+ * 34 MB, whether this entry point is ever called or not.  The scratch used is that of the device x lives on,
+ * which must be the current device (P2N_EINVAL otherwise).  The first call on a device looks the array's address
+ * up (hipGetSymbolAddress) and must therefore happen OUTSIDE stream capture; later calls only launch kernels. */
 #define P2N_NOALLOC_MAX_TILES 256
 int p2n_forward_eval_noalloc(const float *x, int B, int N, int feature_dim, int embedding_dim,
                              const float *packed, float *emb, float *global_f,
@@ -89,6 +93,21 @@ int p2n_forward_eval_bf16(const float *x, int B, int N, int feature_dim, int emb
                           float *f1, float *f2, float *f3,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- "fp32x3": fp32-accurate eval forward on the bf16 matrix pipe (opt-in) ----------------------------
+ * Same computation and results as p2n_forward_eval (reference point2net.py:36-48, 57-65, 67-87) to the SAME
+ * tolerance (1e-5 of max|ref| per tensor): inputs, outputs, spill and tables are fp32; every product w*x is
+ * formed from exact three-way bf16 splits (w = wh+wm+wl, x = xh+xm+xl) as the six part products of weight
+ * >= 2^-16, each exact in fp32, accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (the dropped three are below
+ * the rounding of the accumulation).  Six bf16 MFMAs replace eight fp32 ones at 1/2 the cycles each.
+ * Own packed image and workspace size (workgroups are 256 points).  Python: model.precision = "fp32x3". */
+long p2n_packed_param_count_x3(int feature_dim, int embedding_dim);
+int p2n_pack_eval_params_x3(const float *raw, int feature_dim, int embedding_dim, float *packed, void *stream);
+size_t p2n_forward_eval_x3_workspace_bytes(int B, int N, int feature_dim, int embedding_dim);
+int p2n_forward_eval_x3(const float *x, int B, int N, int feature_dim, int embedding_dim,
+                        const float *packed, float *emb, float *global_f,
+                        float *f1, float *f2, float *f3,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- training path -------------------------------------------------------
  * Train-mode forward (reference point2net.py:36-48,67-87 with model.train(),
  * reference train.py:109,124): BatchNorm uses batch statistics (biased variance),
@@ -100,6 +119,11 @@ int p2n_forward_eval_bf16(const float *x, int B, int N, int feature_dim, int emb
  * untouched workspace plus gemb = dL/d emb (B,N,E) and overwrites the 34 gradient
  * tensors grads_host points at, in the order (W, bias, [bn.weight, bn.bias]) per layer.
  * Weight gradients are summed with fp32 atomics (order not reproducible).
+ * Memory contract of grads_host: the call writes ONLY the bytes of the 34 tensors, with one exception it can
+ * prove harmless: when, sorted by address, the first tensor is 256-byte aligned and every tensor starts exactly at
+ * its predecessor's end rounded up to 256 bytes (one flat bucket, as pointcloudsegmentation_amd/train.py hands
+ * out), the alignment gaps BETWEEN the tensors are zeroed too (one fill instead of nine).  Any other layout is
+ * filled tensor by tensor and nothing outside the tensors is touched.
  * momentum < 0 selects eval-mode BatchNorm for a differentiable forward (model.eval()
  * with autograd enabled, e.g. fine-tuning with frozen statistics): the layers normalise
  * with running_mean/var, which stay untouched, and the backward on that workspace uses

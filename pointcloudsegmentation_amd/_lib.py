@@ -40,6 +40,10 @@ SIGNATURES = {
     "p2n_packed_param_count_bf16": (ctypes.c_long, [c_int, c_int]),
     "p2n_pack_eval_params_bf16": (c_int, [c_f, c_int, c_int, c_f, c_vp]),
     "p2n_forward_eval_bf16": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    "p2n_packed_param_count_x3": (ctypes.c_long, [c_int, c_int]),
+    "p2n_pack_eval_params_x3": (c_int, [c_f, c_int, c_int, c_f, c_vp]),
+    "p2n_forward_eval_x3_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "p2n_forward_eval_x3": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
     "p2n_fps_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "p2n_fps_workgroups_per_cloud": (c_int, [c_int, c_int]),
     "p2n_fps": (c_int, [c_f, c_int, c_int, c_int, c_int, c_i, c_i, c_vp, c_sz, c_vp]),

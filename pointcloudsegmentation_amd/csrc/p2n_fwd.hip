@@ -673,8 +673,18 @@ extern "C" int p2n_forward_eval_noalloc(const float *x, int B, int N, int F, int
                 "p2n_forward_eval_noalloc: B*ceil(N/128) = %ld exceeds the built-in scratch of %d tiles "
                 "(%d points); use p2n_forward_eval with a caller workspace", ntiles, P2N_NOALLOC_MAX_TILES,
                 P2N_NOALLOC_MAX_TILES * P2N_PTS_PER_WG);
+    // The scratch that is used must be the one of the GPU the tensors live on, which is not necessarily the
+    // current device: take it from x itself and refuse a mismatch (the kernels are launched on the current
+    // device; another GPU's scratch address would fault there).
+    P2N_REQUIRE(x, "p2n_forward_eval_noalloc: null x");
     int dev = -1;
     P2N_CHECK_HIP(hipGetDevice(&dev));
+    hipPointerAttribute_t at;
+    P2N_CHECK_HIP(hipPointerGetAttributes(&at, x));
+    P2N_REQUIRE(at.type == hipMemoryTypeDevice, "p2n_forward_eval_noalloc: x is not device memory");
+    P2N_REQUIRE(at.device == dev,
+                "p2n_forward_eval_noalloc: x lives on device %d but the current device is %d: make the tensors' device "
+                "current (hipSetDevice) before the call", at.device, dev);
     P2N_REQUIRE(dev >= 0 && dev < P2N_MAX_DEVICES, "p2n_forward_eval_noalloc: device ordinal %d out of range", dev);
     float *ws;
     {

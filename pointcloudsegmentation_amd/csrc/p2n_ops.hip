@@ -402,9 +402,21 @@ static hipError_t fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
 }
 
 extern "C" int p2n_fps_workgroups_per_cloud(int B, int N) {
+    // the LARGEST cluster p2n_fps(B, N, ...) will actually launch: the same sub-batching and halving as below, so a
+    // cloud that only fits with fewer clouds in flight (B = 64 x 100,000 points) reports its clusters, not 0
     if (B < 1 || N < 1) return 0;
     const int ncu = fps_cus();
-    return fps_plan(B < ncu ? B : ncu, N).G;
+    int done = 0, gmax = 0;
+    while (done < B) {
+        int nb = B - done;
+        if (nb > ncu) nb = ncu;
+        FpsPlan p = fps_plan(nb, N);
+        while (p.G == 0 && nb > 1) { nb = nb / 2; p = fps_plan(nb, N); }
+        if (p.G == 0) return 0;   // p2n_fps refuses this shape
+        gmax = p.G > gmax ? p.G : gmax;
+        done += nb;
+    }
+    return gmax;
 }
 
 extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, int32_t *status,

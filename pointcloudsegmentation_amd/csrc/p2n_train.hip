@@ -1136,23 +1136,33 @@ static int train_backward_run(bool bf, const float *x, const float *gemb, int B,
         // the weight gradients are accumulated with atomics and start from zero.  When all 34 gradient tensors are
         // views of one flat bucket (pointcloudsegmentation_amd/train.py hands them out that way, 256-byte aligned)
         // one fill covers it -- everything else in the span is fully overwritten later in this call -- instead of nine.
-        uintptr_t lo = ~(uintptr_t)0, hi = 0;
-        size_t sum = 0;
+        // The layout is PROVEN, not guessed from proximity: sorted by address, every tensor must start exactly where
+        // its predecessor ends, rounded up to the next 256-byte boundary -- so the span holds nothing but the 34
+        // tensors and their alignment gaps (which belong to the same bucket).  Anything else (tensors allocated one by
+        // one, a foreign block between them) takes the per-tensor fills.
+        struct Ext { uintptr_t a; size_t sz; } ext[34];
         int ng = 0;
         for (int l = 0; l < 9; ++l) {
             const size_t sz[4] = {sizeof(float) * (size_t)n.cin[l] * n.cout[l], sizeof(float) * (size_t)n.cout[l],
                                   sizeof(float) * (size_t)n.cout[l], sizeof(float) * (size_t)n.cout[l]};
             float *ptr[4] = {dW[l], db[l], dgam[l], dbet[l]};
             for (int i = 0; i < (l < 8 ? 4 : 2); ++i) {
-                const uintptr_t a = (uintptr_t)ptr[i];
-                lo = a < lo ? a : lo;
-                hi = a + sz[i] > hi ? a + sz[i] : hi;
-                sum += sz[i];
+                P2N_REQUIRE(ptr[i], "p2n_train_backward: null gradient pointer (layer %d, tensor %d)", l, i);
+                ext[ng].a = (uintptr_t)ptr[i]; ext[ng].sz = sz[i];
                 ++ng;
             }
         }
-        if (hi - lo <= sum + (size_t)ng * 256) {
-            P2N_CHECK_HIP(hipMemsetAsync((void *)lo, 0, hi - lo, s));
+        for (int i = 1; i < ng; ++i) {   // insertion sort by address (34 entries)
+            const Ext e = ext[i];
+            int j = i - 1;
+            for (; j >= 0 && ext[j].a > e.a; --j) ext[j + 1] = ext[j];
+            ext[j + 1] = e;
+        }
+        bool flat = (ext[0].a & 255) == 0;
+        for (int i = 0; flat && i + 1 < ng; ++i)
+            flat = ext[i + 1].a == ((ext[i].a + ext[i].sz + 255) & ~(uintptr_t)255);
+        if (flat) {
+            P2N_CHECK_HIP(hipMemsetAsync((void *)ext[0].a, 0, ext[ng - 1].a + ext[ng - 1].sz - ext[0].a, s));
         } else {
             for (int l = 0; l < 9; ++l) P2N_CHECK_HIP(hipMemsetAsync(dW[l], 0, sizeof(float) * (size_t)n.cin[l] * n.cout[l], s));
         }

@@ -53,12 +53,13 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
     main = torch.cuda.current_stream(dev)
     up, down = _side_streams(dev)
 
-    # Pinned staging is allocated once, before the pipeline starts: a fresh pinned allocation waits for the
-    # busy GPU (hipHostMalloc synchronises with the device) and would serialise the pipeline.  Uploads use two
-    # slots sized for the largest scene; a slot is rewritten only after its previous upload has completed.
+    # Pinned staging is cached per (device, embedding size) and only ever grows: a fresh pinned allocation waits for
+    # the busy GPU (hipHostMalloc synchronises with the device) and costs milliseconds per call -- with a handful of
+    # scenes per call that prologue, not the pipeline, was the time per scene.  Uploads use two slots sized for the
+    # largest scene seen so far; a slot is rewritten only after its previous upload has completed.
     nmax = max(len(p) for p, _ in scenes) if scenes else 0
-    up_ring = [(torch.empty((nmax, 3), dtype=torch.float64, pin_memory=True),
-                torch.empty((nmax, 3), dtype=torch.float64, pin_memory=True), [None]) for _ in range(min(2, len(scenes)))]
+    E = model.embedding_dim
+    up_ring, ring = _pinned_rings(dev, nmax, E)
 
     def stage(k):
         pts, col = scenes[k]
@@ -82,17 +83,11 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
         last[0] = copied
         return feat, cs, ev
 
-    # Results leave through a ring of three pinned slots sized for the largest scene and are copied out into
-    # ordinary arrays when yielded: a fresh pinned allocation per scene would wait for the busy GPU
-    # (hipHostMalloc synchronises with the device) and serialise the pipeline.
-    E = model.embedding_dim
-    ring = [(torch.empty(nmax, dtype=torch.int64, pin_memory=True), torch.empty((nmax, E), dtype=torch.float32, pin_memory=True),
-             torch.empty(4, dtype=torch.float64, pin_memory=True), torch.empty(1, dtype=torch.int64, pin_memory=True))
-            for _ in range(min(3, len(scenes)))]
-
+    # Results leave through a ring of three pinned slots (same cache) and are copied out into ordinary arrays when
+    # yielded.
     def finish(job):
         slot, n, ev = job
-        labels_h, emb_h, cs_h, num_h = ring[slot]
+        labels_h, emb_h, cs_h, num_h, _ = ring[slot]
         ev.synchronize()
         cs = cs_h.numpy()
         return {"instance_labels": labels_h[:n].numpy().copy(), "embeddings": emb_h[:n].numpy().copy(),
@@ -113,7 +108,7 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
         n = labels.shape[0]
         done = torch.cuda.Event()
         done.record(main)
-        labels_h, emb_h, cs_h, num_h = ring[i % 3]
+        labels_h, emb_h, cs_h, num_h, out_last = ring[i % 3]
         with torch.cuda.stream(down):                        # results leave while scene i+1 computes
             down.wait_event(done)
             labels_h[:n].copy_(labels, non_blocking=True)
@@ -124,6 +119,7 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
                 t.record_stream(down)
             out_ev = torch.cuda.Event()
             out_ev.record(down)
+        out_last[0] = out_ev
         if pending is not None:
             yield finish(pending)
         pending = (i % 3, n, out_ev)
@@ -132,6 +128,33 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
 
 
 _streams = {}
+_rings = {}
+
+
+def _pinned_rings(dev: torch.device, nmax: int, E: int):
+    """The pinned upload slots (2) and result slots (3) of predict_many for this device and embedding size, sized
+    for the largest scene seen so far.  Every slot carries the event of its last transfer: a call that finds one
+    pending (an earlier generator abandoned half-way) waits for it before the slot is reused."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), E)
+    ent = _rings.get(key)
+    if ent is None or ent[0] < nmax:
+        cap = max(nmax, 1)
+        up = [(torch.empty((cap, 3), dtype=torch.float64, pin_memory=True),
+               torch.empty((cap, 3), dtype=torch.float64, pin_memory=True), [None]) for _ in range(2)]
+        out = [(torch.empty(cap, dtype=torch.int64, pin_memory=True), torch.empty((cap, E), dtype=torch.float32, pin_memory=True),
+                torch.empty(4, dtype=torch.float64, pin_memory=True), torch.empty(1, dtype=torch.int64, pin_memory=True), [None])
+               for _ in range(3)]
+        ent = (cap, up, out)
+        _rings[key] = ent
+    for slot in ent[1]:
+        if slot[2][0] is not None:
+            slot[2][0].synchronize()
+            slot[2][0] = None
+    for slot in ent[2]:
+        if slot[4][0] is not None:
+            slot[4][0].synchronize()
+            slot[4][0] = None
+    return ent[1], ent[2]
 
 
 def _side_streams(dev: torch.device):

@@ -18,17 +18,32 @@ import torch
 import torch.distributed as dist
 
 
+_gloo_device_ok = None    # decided once per process, by a probe every rank takes together
+
+
+def _gloo_reduces_device_tensors(device: torch.device) -> bool:
+    """gloo only: can this build all-reduce a device tensor?  One 1-element probe, entered by all ranks at the
+    same point of their first device all-reduce, so every rank takes the same path afterwards."""
+    global _gloo_device_ok
+    if _gloo_device_ok is None:
+        try:
+            dist.all_reduce(torch.zeros(1, device=device))
+            _gloo_device_ok = True
+        except RuntimeError:
+            _gloo_device_ok = False
+    return _gloo_device_ok
+
+
 def _all_reduce_mean(flat: torch.Tensor, world: int) -> None:
-    """In-place mean over ranks.  A backend without support for device tensors (a gloo build without it)
-    gets the bucket through a host copy; RCCL ("nccl") and gloo-with-devices reduce it where it is."""
-    try:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    except RuntimeError:
-        if not flat.is_cuda:
-            raise
+    """In-place mean over ranks.  Under RCCL ("nccl") the bucket is reduced where it is and any error of the
+    collective propagates (a retry on one rank only would desynchronise the job).  The host-copy path exists for
+    gloo builds without device support and is chosen by the backend, never by catching a failed collective."""
+    if flat.is_cuda and dist.get_backend() == "gloo" and not _gloo_reduces_device_tensors(flat.device):
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(world)
 
 

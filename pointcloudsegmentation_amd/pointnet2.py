@@ -533,7 +533,11 @@ class Point2NetSA(nn.Module):
         dev = x.device
         main = torch.cuda.current_stream(dev)
         xyz0 = x[:, :, :3].contiguous()
-        if not self.overlap_geometry:
+        # Clouds sampled by workgroup CLUSTERS (> 12,288 points) are planned as if they owned every CU: beside the level
+        # kernels of other streams their workgroups may not all be resident and the exchange would time out.  They run
+        # the whole forward in order on the caller's stream instead (no overlap, nothing to time out against).
+        clusters = ops.fps_needs_check(x.shape[0], x.shape[1])
+        if not self.overlap_geometry or clusters:
             xyz1, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c)                     # level 1 reads x's rows in place
             xyz2, f2 = self.sa2.forward_rows(xyz1, f1, f1.shape[2], 0, f1.shape[2])
             xyz3, f3 = self.sa3.forward_rows(xyz2, f2, f2.shape[2], 0, f2.shape[2])
@@ -544,8 +548,8 @@ class Point2NetSA(nn.Module):
             start = torch.cuda.Event()
             start.record(main)
             emb = self._levels(x, xyz0, self._geometry(xyz0, start))
-        if ops.fps_needs_check(x.shape[0], x.shape[1]):
-            ops.fps_check(x.device)      # clouds sampled by workgroup clusters: a timed-out exchange raises here
+        if clusters:
+            ops.fps_check(x.device)      # a timed-out exchange (another process's kernels on the GPU) raises here
         return emb
 
 
@@ -625,6 +629,8 @@ class Point2NetSA(nn.Module):
         for x in batches:
             if x.dim() != 3 or x.size(2) != self.feature_dim:
                 raise ValueError(f"expected batches of shape (B, N, {self.feature_dim}), got {tuple(x.shape)}")
+        if any(ops.fps_needs_check(x.shape[0], x.shape[1]) for x in batches):
+            return [self._forward_fused(x) for x in batches]   # workgroup clusters must own the chip: no pipelining
         dev = x0.device
         main = torch.cuda.current_stream(dev)
         xs = [_rt.require_cuda_f32(x, "x") for x in batches]
@@ -640,8 +646,6 @@ class Point2NetSA(nn.Module):
             j = i + GEO_LANES
             if j < len(xs):
                 geo[j] = self._geometry(xyz0[j], start, j % GEO_LANES)
-        if any(ops.fps_needs_check(x.shape[0], x.shape[1]) for x in xs):
-            ops.fps_check(dev)
         return out
 
 

@@ -63,7 +63,15 @@ def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-PRECISIONS = ("fp32", "bf16")
+PRECISIONS = ("fp32", "bf16", "fp32x3")
+# precision -> (packed size, pack, workspace size, forward) entry points of the C ABI
+_EVAL_ENTRY = {
+    "fp32": ("p2n_packed_param_count", "p2n_pack_eval_params", "p2n_forward_eval_workspace_bytes", "p2n_forward_eval"),
+    "bf16": ("p2n_packed_param_count_bf16", "p2n_pack_eval_params_bf16", "p2n_forward_eval_workspace_bytes",
+             "p2n_forward_eval_bf16"),
+    "fp32x3": ("p2n_packed_param_count_x3", "p2n_pack_eval_params_x3", "p2n_forward_eval_x3_workspace_bytes",
+               "p2n_forward_eval_x3"),
+}
 
 
 def pack_eval_params(raw: torch.Tensor, feature_dim: int, embedding_dim: int, precision: str = "fp32") -> torch.Tensor:
@@ -71,8 +79,7 @@ def pack_eval_params(raw: torch.Tensor, feature_dim: int, embedding_dim: int, pr
     L = _lib.lib()
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
-    count = L.p2n_packed_param_count if precision == "fp32" else L.p2n_packed_param_count_bf16
-    pack = L.p2n_pack_eval_params if precision == "fp32" else L.p2n_pack_eval_params_bf16
+    count, pack = getattr(L, _EVAL_ENTRY[precision][0]), getattr(L, _EVAL_ENTRY[precision][1])
     n = count(feature_dim, embedding_dim)
     if n < 0:
         raise ValueError(f"unsupported feature_dim={feature_dim} / embedding_dim={embedding_dim} "
@@ -92,7 +99,9 @@ def forward_eval(x: torch.Tensor, packed: torch.Tensor, embedding_dim: int, want
     """x (B,N,F) -> emb (B,N,E) [, global_f (B,256)] [, f1, f2, f3].  `packed` must have been built
     for the same precision."""
     L = _lib.lib()
-    fwd = L.p2n_forward_eval if precision == "fp32" else L.p2n_forward_eval_bf16
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+    ws_bytes, fwd = getattr(L, _EVAL_ENTRY[precision][2]), getattr(L, _EVAL_ENTRY[precision][3])
     x = require_cuda_f32(x, "x")
     if x.dim() != 3:
         raise ValueError(f"x must be (B,N,C), got {tuple(x.shape)}")
@@ -105,7 +114,7 @@ def forward_eval(x: torch.Tensor, packed: torch.Tensor, embedding_dim: int, want
     f2 = torch.empty((B, 128, N), dtype=torch.float32, device=dev) if want_features else None
     f3 = torch.empty((B, 256, N), dtype=torch.float32, device=dev) if want_features else None
     if B * N > 0:
-        nbytes = L.p2n_forward_eval_workspace_bytes(B, N, F, E)
+        nbytes = ws_bytes(B, N, F, E)
         ws = workspace(nbytes, dev)
         with torch.cuda.device(dev):
             _lib.check(fwd(x.data_ptr(), B, N, F, E, packed.data_ptr(), ptr(emb), ptr(g), ptr(f1), ptr(f2), ptr(f3),

@@ -57,20 +57,29 @@ out["cluster_ms_33_cluster_embeddings"], _ = timed(lambda: cluster_embeddings(sy
 # (upload of scene i+1 and download of scene i-1 beside the compute of scene i)
 from pointcloudsegmentation_amd.inference import predict_many
 out["scene_stream"] = {}
+NSC = 20     # scenes per call: a handful would measure the call's prologue, not the pipeline
 for n_s in (40000, 80000, 150000):
     sc = []
-    for k in range(6):
+    for k in range(NSC):
         r2 = np.random.default_rng(100 + k)
         sc.append(((r2.uniform(0, 1, (n_s, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64), r2.integers(0, 256, (n_s, 3)).astype(np.float64)))
     row = {}
     for mode, ov in (("serial", False), ("pipelined", True)):
         for _ in range(2):      # the caching allocators (device blocks per stream, pinned blocks) reach their steady state
-            list(predict_many(m, sc, overlap=ov))
+            list(predict_many(m, sc[:4], overlap=ov))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res_s = list(predict_many(m, sc, overlap=ov))
+        stamps = []
+        for _res in predict_many(m, sc, overlap=ov):
+            stamps.append(time.perf_counter())
         torch.cuda.synchronize()
-        row[mode + "_ms_per_scene"] = 1e3 * (time.perf_counter() - t0) / len(sc)
+        t1 = time.perf_counter()
+        gaps = np.diff(np.array([t0] + stamps)) * 1e3
+        row[mode + "_ms_per_scene"] = 1e3 * (t1 - t0) / len(sc)
+        row[mode + "_first_result_ms"] = float(gaps[0])          # prologue + the pipeline's fill
+        row[mode + "_ms_per_scene_min"] = float(gaps[1:].min())
+        row[mode + "_ms_per_scene_median"] = float(np.median(gaps[1:]))
+    row["scenes_per_call"] = NSC
     row["speedup"] = row["serial_ms_per_scene"] / row["pipelined_ms_per_scene"]
     out["scene_stream"][str(n_s)] = row
 if not a.no_cpu:
