@@ -210,7 +210,7 @@ def train_leg(device, steps=10):
     pts = x[:, :, :3].contiguous()
     out = {"workload": "train fwd + InstanceSegLoss + bwd + clip_grad_norm_ + Adam (reference train.py:118-136), "
                        "B=32 x 8192, random-init weights, synthetic labels", "steps": steps}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "fp32x3", "bf16"):
         torch.manual_seed(0)
         model = Point2Net(6, 64).to(device).train()
         model.precision = prec
@@ -240,6 +240,10 @@ def train_leg(device, steps=10):
                      "frac_of_fp32_mfma_peak": 3 * FLOP_PER_PT_STEP * B * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del model, opt
     del out["bf16"]["frac_of_fp32_mfma_peak"]   # HBM-bound in this mode: the fp32 MFMA peak is not its roofline
+    del out["fp32x3"]["frac_of_fp32_mfma_peak"]   # runs on the bf16 matrix pipe: six part products per algorithmic MAC
+    out["fp32x3"]["dtype"] = "f32 in/out, 3xbf16 split products (6 of 9 part products), fp32 accumulate"
+    out["fp32x3"]["note"] = ("opt-in (model.precision = 'fp32x3'): same reference goldens at the same tolerances as fp32 "
+                             "(tests/test_train_x3_gpu.py); first layer (K = 6) on the fp32 MFMA")
     out["bf16"]["note"] = "GEMM operands rounded to bf16, fp32 accumulation and storage"
     torch.cuda.empty_cache()
     return out

@@ -149,6 +149,18 @@ int p2n_train_forward_bf16(const float *x, int B, int N, int feature_dim, int em
 int p2n_train_backward_bf16(const float *x, const float *gemb, int B, int N, int feature_dim, int embedding_dim,
                             const void *const *params_host, void *const *grads_host,
                             void *workspace, size_t workspace_bytes, void *stream);
+/* The same two calls in "fp32x3" mode (see p2n_forward_eval_x3): every GEMM operand of reference point2net.py:36-48,57-65 and
+ * of its backward is split EXACTLY into three bf16 parts (weights at pack time, activations and gradients in the
+ * operand loaders) and the six part products of weight >= 2^-16 accumulate in fp32 on v_mfma_f32_32x32x16_bf16: the
+ * fp32 mode's results to fp32 accuracy -- same reference goldens, same tolerances -- at 6/16 of its matrix-pipe cycles.
+ * The first layer (reduction length = feature_dim) stays on the fp32 MFMA.  Same arguments and workspace; a forward
+ * and its backward must use the same precision.  Python: model.precision = "fp32x3". */
+int p2n_train_forward_x3(const float *x, int B, int N, int feature_dim, int embedding_dim,
+                         const void *const *params_host, float momentum, float *emb, float *global_f,
+                         float *f1, float *f2, float *f3, void *workspace, size_t workspace_bytes, void *stream);
+int p2n_train_backward_x3(const float *x, const float *gemb, int B, int N, int feature_dim, int embedding_dim,
+                          const void *const *params_host, void *const *grads_host,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Shared MLP of a hierarchical level in train() mode (no reference counterpart: the north star names
  * set-abstraction / feature-propagation levels, the reference has none; semantics = torch's

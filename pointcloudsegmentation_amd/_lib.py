@@ -61,6 +61,8 @@ SIGNATURES = {
     "p2n_train_backward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "p2n_train_forward_bf16": (c_int, [c_f, c_int, c_int, c_int, c_int, c_vp, c_float, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
     "p2n_train_backward_bf16": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "p2n_train_forward_x3": (c_int, [c_f, c_int, c_int, c_int, c_int, c_vp, c_float, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    "p2n_train_backward_x3": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "p2n_mlp_train_workspace_bytes": (c_sz, [ctypes.c_long, c_int, c_vp, c_int]),
     "p2n_mlp_train_forward": (c_int, [c_f, ctypes.c_long, c_int, c_vp, c_int, c_vp, c_float, c_f, c_vp, c_sz, c_vp]),
     "p2n_mlp_train_backward": (c_int, [c_f, c_f, ctypes.c_long, c_int, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_sz, c_vp]),

@@ -158,6 +158,12 @@ __global__ void p2n_pack_x3_kernel(const float *__restrict__ raw, float *__restr
 // ------------------------------------------------------------------ split and multiply
 // registers r0..r0+7 of an accumulator tile = the fragment of one k-step -> its three bf16 parts
 __device__ __forceinline__ void split8(const f32x16 &v, int r0, bf16x8 &xh, bf16x8 &xm, bf16x8 &xl) {
+#if defined(X3_EXP) && (X3_EXP & 1)   // timing experiment (wrong results): no split arithmetic
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 a = {v[r0], v[r0 + 1], v[r0 + 2], v[r0 + 3]}, b = {v[r0 + 4], v[r0 + 5], v[r0 + 6], v[r0 + 7]};
+    xh = __builtin_bit_cast(bf16x8, a); xm = __builtin_bit_cast(bf16x8, b); xl = xh;
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float a = v[r0 + j];
@@ -205,6 +211,9 @@ __device__ __forceinline__ void x3_ctx_init(X3Ctx &c, const float *stream, float
 // chunk gate at fragment f; chunk 0 is entered explicitly at the top of each kernel (its barrier is also what makes
 // the tables visible, so it has to precede the first accumulator start)
 __device__ __forceinline__ void gate_x(int f, X3Ctx &c) {
+#if defined(X3_EXP) && (X3_EXP & 2)   // timing experiment (wrong results): no chunk hand-over (no barrier, no DMA)
+    return;
+#endif
     if (f % P2N_CHUNK == 0 && f != 0) enter_chunk_b(f / P2N_CHUNK, c.stream, c.wbuf, c.wave, c.lane);
 }
 __device__ __forceinline__ bf16x8 frag_x(const X3Ctx &c, int f) {

@@ -62,6 +62,22 @@ __global__ void p2n_pack_w_bf16_kernel(const float *__restrict__ W, int ldw, int
     img[i] = (__bf16)v;
 }
 
+// fp32x3 image (three-way bf16 split of every weight, w = h + m + l exactly): fragment f = (ks*CT + ct)*3 + part covers
+// k = 16ks .. 16ks+15 of output tile ct: img[f][lane][i] (8 bf16 per lane) = part(M[32ct + (lane&31)][16ks + 8(lane>>5) + i]).
+__global__ void p2n_pack_w_x3_kernel(const float *__restrict__ W, int ldw, int col0, int rows_real, int k_real, int trans,
+                                     __bf16 *__restrict__ img, int CT, int KT) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)CT * KT * 6 * 512) return;
+    const int e = (int)(i & 511), lane = e >> 3, j = e & 7;
+    const int f = (int)(i >> 9);
+    const int part = f % 3, ct = (f / 3) % CT, ks = (f / 3) / CT;
+    const int row = 32 * ct + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (row < rows_real && k < k_real) v = trans ? W[(long)k * ldw + col0 + row] : W[(long)row * ldw + col0 + k];
+    const float h = (float)(__bf16)v, r1 = v - h, m = (float)(__bf16)r1, r2 = r1 - m;
+    img[i] = (__bf16)(part == 0 ? h : part == 1 ? m : r2);
+}
+
 // first of the four rows (k0 .. k0+3) that register group g of lane half h holds in k-tile kt: fp32 MFMA operands take
 // k = 8g + 4h + j, the bf16 ones k = 16(g>>1) + 8h + 4(g&1) + j (registers 8s .. 8s+7 = the fragment of k-step s)
 template <bool BF>
@@ -224,16 +240,44 @@ __device__ __forceinline__ void tl_store_dz(const LayerArgs &A, int kt, long pg,
 // K4: the reduction length is a multiple of eight (of sixteen in bf16 mode) -- every layer of the model; only first
 // layers of hierarchical levels are not -- so the row bound is wave-uniform per group of rows and channel-major
 // addresses are scalar bases plus one lane offset (tl_urow).
-template <int MODE, int CT, bool OUT_PM, bool K4, bool BF = false>
+// the six part products of one (k-step, output tile) in fp32x3 mode (p2n_fwd_x3.hip): w = wh+wm+wl, x = xh+xm+xl
+__device__ __forceinline__ f32x16 tl_mma6(f32x16 acc, const bf16x8 wh, const bf16x8 wm, const bf16x8 wl, const bf16x8 xh,
+                                          const bf16x8 xm, const bf16x8 xl) {
+    acc = MFMAB(wh, xl, acc);
+    acc = MFMAB(wh, xm, acc);
+    acc = MFMAB(wh, xh, acc);
+    acc = MFMAB(wm, xm, acc);
+    acc = MFMAB(wm, xh, acc);
+    acc = MFMAB(wl, xh, acc);
+    return acc;
+}
+// eight fp32 values -> their exact three-way bf16 split
+__device__ __forceinline__ void tl_split8(const f32x16 &v, int r0, bf16x8 &xh, bf16x8 &xm, bf16x8 &xl) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = v[r0 + j];
+        xh[j] = (__bf16)a;
+        const float r1 = a - (float)xh[j];
+        xm[j] = (__bf16)r1;
+        xl[j] = (__bf16)(r1 - (float)xm[j]);
+    }
+}
+
+// PREC: 0 = exact fp32 MFMA, 1 = bf16 operands, 2 = "fp32x3" (operands split three ways into bf16 in the loader, six
+// exact part products per k-step on the bf16 MFMA, fp32 accumulate: fp32 accuracy at 6/16 of the fp32 MFMA's cycles)
+template <int MODE, int CT, bool OUT_PM, bool K4, int PREC = 0>
 __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerArgs A) {
     // Up to 128 output rows (64 accumulator registers): three workgroups per CU -- 16-KiB weight chunks keep the LDS of
     // three within 160 KiB, the registers fit three waves per SIMD -- so that while two waves of a SIMD alternate
     // their MFMA blocks a third is there for the phases between blocks.
-    constexpr int CHF = CT <= 4 ? 16 : 32;      // weight fragments (1 KiB) per chunk
+    constexpr bool BF = PREC != 0;              // operand registers in the bf16 MFMA's order (eight consecutive k per k-step)
+    constexpr bool X3 = PREC == 2;
+    constexpr bool HALF = X3 && CT >= 4;        // fp32x3, wide layers: a chunk is ONE k-step (3 CT fragments), two hand-overs per k-tile
+    constexpr int CHF = X3 ? (CT >= 4 ? 3 * CT : 12) : (CT <= 4 ? 16 : 32);      // weight fragments (1 KiB) per chunk
     __shared__ __attribute__((aligned(16))) float wbuf[2 * CHF * 256];
     __shared__ __attribute__((aligned(16))) float tab[5 * 256];
-    constexpr int FPK = BF ? 2 * CT : 4 * CT;   // 1-KiB weight fragments per k-tile
-    constexpr int KPC = CHF / FPK;   // k-tiles per weight chunk
+    constexpr int FPK = X3 ? 6 * CT : BF ? 2 * CT : 4 * CT;   // 1-KiB weight fragments per k-tile
+    constexpr int KPC = HALF ? 1 : CHF / FPK;   // k-tiles per weight chunk (HALF: two chunks per k-tile, handled below)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int p = lane & 31, h = lane >> 5;
     const long bbase = (long)blockIdx.x * 128;   // the workgroup's first column
@@ -264,13 +308,52 @@ __global__ __launch_bounds__(256, TL_WGS(CT)) void p2n_train_layer_kernel(LayerA
     if (MODE == LD_BNBWD && A.dz_out) tl_store_dz<K4, BF>(A, 0, pg, h, cur, bbase, voffb);
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt % KPC == 0) {
+        if (HALF) {   // chunk 2kt (this k-tile's first k-step) has landed; the other buffer takes chunk 2kt+1
+            if (kt) p2n_dma_barrier();
+            tl_stage<CHF>(A.wimg, wbuf, 2 * kt + 1, wave, lane);
+        } else if (kt % KPC == 0) {
             if (kt) p2n_dma_barrier();   // chunk kt/KPC has landed (vmcnt(0) + barrier); the other buffer is free
             if ((kt / KPC + 1) * KPC < KT) tl_stage<CHF>(A.wimg, wbuf, kt / KPC + 1, wave, lane);   // never a chunk nobody reads: nothing is pending when the workgroup ends
         }
         if (kt + 1 < KT) tl_fetch<MODE, K4, BF>(A, kt + 1, pg, valid, h, r0, r1, bbase, voffb);   // queued behind the DMA, consumed after the MFMAs
         const float *wb = wbuf + ((kt / KPC) & 1) * (CHF * 256) + (kt % KPC) * (FPK * 256) + lane * 4;
-        if (BF) {
+        if (X3) {
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const float *wq = wb + sx * (3 * CT * 256);
+                if (HALF) {
+                    if (sx == 1) {
+                        // second hand-over of the k-tile: chunk 2kt+1 was queued at the top, IN FRONT of the operand
+                        // prefetch, whose loads need not have landed -- but the wait is the plain one: a counted wait
+                        // would have to know how many loads the compiler left in the queue behind the DMA
+                        p2n_dma_barrier();
+                        if (kt + 1 < KT) tl_stage<CHF>(A.wimg, wbuf, 2 * kt + 2, wave, lane);
+                    }
+                    wq = wbuf + ((2 * kt + sx) & 1) * (CHF * 256) + lane * 4;
+                }
+                bf16x8 xh, xm, xl;
+                tl_split8(cur, 8 * sx, xh, xm, xl);
+                bf16x8 wh = *reinterpret_cast<const bf16x8 *>(wq), wm = *reinterpret_cast<const bf16x8 *>(wq + 256),
+                       wl = *reinterpret_cast<const bf16x8 *>(wq + 512);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    // the fragment registers are refilled for the next tile as soon as their last MFMA has issued
+                    // (p2n_fwd_x3.hip: step_x3), MFMA / LDS-read order pinned, vector-ALU instructions free to move
+                    acc[ct] = MFMAB(wh, xl, acc[ct]);
+                    acc[ct] = MFMAB(wh, xm, acc[ct]);
+                    acc[ct] = MFMAB(wh, xh, acc[ct]);
+                    if (ct + 1 < CT) wh = *reinterpret_cast<const bf16x8 *>(wq + ((ct + 1) * 3) * 256);
+                    __builtin_amdgcn_sched_barrier(0x6);
+                    acc[ct] = MFMAB(wm, xm, acc[ct]);
+                    acc[ct] = MFMAB(wm, xh, acc[ct]);
+                    if (ct + 1 < CT) wm = *reinterpret_cast<const bf16x8 *>(wq + ((ct + 1) * 3 + 1) * 256);
+                    __builtin_amdgcn_sched_barrier(0x6);
+                    acc[ct] = MFMAB(wl, xh, acc[ct]);
+                    if (ct + 1 < CT) wl = *reinterpret_cast<const bf16x8 *>(wq + ((ct + 1) * 3 + 2) * 256);
+                    __builtin_amdgcn_sched_barrier(0x6);
+                }
+            }
+        } else if (BF) {
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
                 bf16x8 bfrag;
@@ -611,6 +694,172 @@ __global__ __launch_bounds__(256, 2) void p2n_wgrad_kernel(WgArgs A) {   // two 
         }
 }
 
+// ---------------------------------------------------------------- wgrad, fp32x3 mode
+// dW = dz . a^T with both operands split EXACTLY into three bf16 parts when they are parked (once per element and
+// workgroup; the fused transforms run in fp32 first, as in the fp32 kernel) and the six part products of weight >= 2^-16
+// on the bf16 MFMA, fp32 accumulate.  Same block shapes, slices and atomic epilogue as p2n_wgrad_kernel; a step is 32
+// points, so that the three parts of a 128 x 128 block (60 KiB) still leave room for two workgroups per CU.
+#define WX_PTS 32
+#define WX_LD (WX_PTS + 8)                 // bf16 elements per parked row (80 bytes: 16-byte fragments stay aligned)
+#define WX_TILE (WG_TILE * WX_LD)          // bf16 elements of one part of a 64-row tile
+
+template <int MODE>
+struct WxStage {
+    f32x4 v0[2], v1[2];
+};
+
+template <int MODE>
+__device__ __forceinline__ void wx_fetch(WxStage<MODE> &st, const float *__restrict__ s0, const float *__restrict__ s1,
+                                         int row0, int nrows, long p0, long pend, int Ppad, int ld) {
+    const int t = threadIdx.x;   // every load unconditional on clamped addresses (see wgrad_fetch)
+    if (MODE == LD_BNBWD || MODE == LD_BNRELU || MODE == LD_PLAIN) {
+        const int seg = (t & 3) * 8;
+        int row = row0 + (t >> 2);
+        row = row < nrows ? row : nrows - 1;
+        const float *q0 = s0 + (long)row * Ppad + p0 + seg;
+        st.v0[0] = *reinterpret_cast<const f32x4 *>(q0);
+        st.v0[1] = *reinterpret_cast<const f32x4 *>(q0 + 4);
+        if (MODE == LD_BNBWD) {
+            const float *q1 = s1 + (long)row * Ppad + p0 + seg;
+            st.v1[0] = *reinterpret_cast<const f32x4 *>(q1);
+            st.v1[1] = *reinterpret_cast<const f32x4 *>(q1 + 4);
+        }
+    } else {   // point-major sources: gemb (P,E) or x (P,F)
+        const int seg = (t >> 6) * 8;
+        int row = row0 + (t & 63);
+        row = row < nrows ? row : nrows - 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            long p = p0 + seg + i;
+            p = p < pend ? p : pend - 1;
+            st.v0[i >> 2][i & 3] = s0[p * ld + row];
+        }
+    }
+}
+
+// transform (fp32, as wgrad_park), zero what lies outside the block, split, store 8 consecutive points of one row as
+// one 16-byte piece per part: dst[part][row][point]
+template <int MODE>
+__device__ __forceinline__ void wx_park(const WxStage<MODE> &st, __bf16 *__restrict__ dst, const WgConst &c, int row0,
+                                        int nrows, long p0, long pend) {
+    const int t = threadIdx.x;
+    const bool cm = MODE == LD_BNBWD || MODE == LD_BNRELU || MODE == LD_PLAIN;
+    const int r = cm ? t >> 2 : t & 63, seg = cm ? (t & 3) * 8 : (t >> 6) * 8;
+    const bool rok = row0 + r < nrows;
+    bf16x8 oh, om, ol;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = st.v0[i >> 2][i & 3];
+        if (MODE == LD_BNBWD) {
+            const float z = st.v1[i >> 2][i & 3];
+            const float dy = fmaf(z, c.c0, c.c1) > 0.f ? v : 0.f;
+            v = fmaf(c.c4, z, fmaf(c.c2, dy, c.c3));
+        } else if (MODE == LD_BNRELU) {
+            v = fmaxf(fmaf(v, c.c0, c.c1), 0.f);
+        }
+        v = (rok && p0 + seg + i < pend) ? v : 0.f;
+        oh[i] = (__bf16)v;
+        const float r1 = v - (float)oh[i];
+        om[i] = (__bf16)r1;
+        ol[i] = (__bf16)(r1 - (float)om[i]);
+    }
+    __bf16 *d = dst + r * WX_LD + seg;
+    *reinterpret_cast<bf16x8 *>(d) = oh;
+    *reinterpret_cast<bf16x8 *>(d + WX_TILE) = om;
+    *reinterpret_cast<bf16x8 *>(d + 2 * WX_TILE) = ol;
+}
+
+template <int AMODE, int BMODE, int RT, int CT>
+__global__ __launch_bounds__(256, 2) void p2n_wgrad_x3_kernel(WgArgs A) {
+    __shared__ __attribute__((aligned(16))) __bf16 sa[RT * 3 * WX_TILE], sb[CT * 3 * WX_TILE];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int br = blockIdx.x / A.ntc, bc = blockIdx.x % A.ntc;
+    const long s0 = (long)blockIdx.y * A.slice;
+    long s1 = s0 + A.slice;
+    if (s1 > A.P) s1 = A.P;
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int k = 0; k < CT; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][k][e] = 0.f;
+    WxStage<AMODE> sta[RT];
+    WxStage<BMODE> stb[CT];
+    auto fetch = [&](long p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) wx_fetch<AMODE>(sta[i], A.a0, A.a1, (br * RT + i) * WG_TILE, A.rows, p0, s1, A.Ppad, A.ld_a);
+#pragma unroll
+        for (int k = 0; k < CT; ++k) wx_fetch<BMODE>(stb[k], A.b0, nullptr, (bc * CT + k) * WG_TILE, A.cols, p0, s1, A.Ppad, A.ld_b);
+    };
+    WgConst ca[RT], cb[CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) ca[i] = wgrad_const<AMODE>(A.atab, (br * RT + i) * WG_TILE, A.rows, A.rows);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) cb[k] = wgrad_const<BMODE>(A.btab, (bc * CT + k) * WG_TILE, A.cols, A.cols);
+    auto park = [&](long p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) wx_park<AMODE>(sta[i], sa + i * 3 * WX_TILE, ca[i], (br * RT + i) * WG_TILE, A.rows, p0, s1);
+#pragma unroll
+        for (int k = 0; k < CT; ++k) wx_park<BMODE>(stb[k], sb + k * 3 * WX_TILE, cb[k], (bc * CT + k) * WG_TILE, A.cols, p0, s1);
+    };
+    if (s0 < s1) {
+        fetch(s0);
+        park(s0);
+    }
+    for (long p0 = s0; p0 < s1; p0 += WX_PTS) {
+        __syncthreads();   // the block of step p0 is in LDS
+        const bool more = p0 + WX_PTS < s1;
+        if (more) fetch(p0 + WX_PTS);   // in flight while the MFMAs run
+#pragma unroll
+        for (int ks = 0; ks < WX_PTS / 16; ++ks) {
+            bf16x8 ah[RT], am[RT], al[RT], bh[CT], bm[CT], bl[CT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int tile32 = wr * RT + i;   // 32-row tile of the block: 64-row parked tile tile32/2, half tile32%2
+                const __bf16 *q = sa + (tile32 / 2) * 3 * WX_TILE + (32 * (tile32 % 2) + r) * WX_LD + 8 * h + 16 * ks;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(q);
+                am[i] = *reinterpret_cast<const bf16x8 *>(q + WX_TILE);
+                al[i] = *reinterpret_cast<const bf16x8 *>(q + 2 * WX_TILE);
+            }
+#pragma unroll
+            for (int k = 0; k < CT; ++k) {
+                const int tile32 = wc * CT + k;
+                const __bf16 *q = sb + (tile32 / 2) * 3 * WX_TILE + (32 * (tile32 % 2) + r) * WX_LD + 8 * h + 16 * ks;
+                bh[k] = *reinterpret_cast<const bf16x8 *>(q);
+                bm[k] = *reinterpret_cast<const bf16x8 *>(q + WX_TILE);
+                bl[k] = *reinterpret_cast<const bf16x8 *>(q + 2 * WX_TILE);
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int k = 0; k < CT; ++k) acc[i][k] = tl_mma6(acc[i][k], ah[i], am[i], al[i], bh[k], bm[k], bl[k]);
+        }
+        if (more) {
+            __syncthreads();   // everybody has read this step's block
+            park(p0 + WX_PTS);
+        }
+    }
+    if (s0 >= s1) return;
+    // D: column = lane&31 (input channel), rows = 8g+4h+j (output channel)
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int k = 0; k < CT; ++k) {
+            const int oc = bc * CT * WG_TILE + 32 * (wc * CT + k) + r;
+            if (oc >= A.cols) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int orow = br * RT * WG_TILE + 32 * (wr * RT + i) + 8 * g + 4 * h + j;
+                    if (orow < A.rows) atomicAdd(&A.dW[(long)orow * A.ldw + oc], acc[i][k][4 * g + j]);
+                }
+        }
+}
+
 // ---------------------------------------------------------------- row statistics
 // grid (rows, S): two pivot-free partial sums per (row, slice) into part[(row*S+s)*2].
 //   ST_FWD     sum (z - pivot), sum (z - pivot)^2          pivot = z[row][0]
@@ -902,7 +1151,7 @@ size_t carve(Net &n, char *base) {
     for (int l = 0; l < 8; ++l) n.ftab[l] = (float *)take(sizeof(float) * 4 * n.cout[l]);
     n.btab = (float *)take(sizeof(float) * 5 * 256);
     n.part = (float *)take(sizeof(float) * 2 * 256 * STAT_S);
-    n.wimg = (float *)take(sizeof(float) * (256 * 256 + 2 * 32 * 256));   // + spare chunks the prefetch may touch
+    n.wimg = (float *)take(sizeof(float) * (256 * 256 * 3 / 2 + 2 * 32 * 256));   // fp32x3: three bf16 per weight; + spare chunks the prefetch may touch
     n.g = (float *)take(sizeof(float) * (size_t)n.B * 256);
     n.bias6c = (float *)take(sizeof(float) * (size_t)n.B * 256);
     n.dzsum6 = (float *)take(sizeof(float) * (size_t)n.B * 256);
@@ -937,9 +1186,16 @@ int ct_pad(int rows) {   // output tiles rounded up to a power of two (the kerne
     return ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
 }
 
-int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float *img, hipStream_t s, bool bf = false) {
+int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float *img, hipStream_t s, int prec = 0) {
     const int CT = ct_pad(rows), KT = (k + 31) / 32;
-    if (bf) {
+    if (prec == 2) {
+        const long n = (long)CT * KT * 6 * 512;
+        hipLaunchKernelGGL(p2n_pack_w_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, col0, rows, k,
+                           trans, reinterpret_cast<__bf16 *>(img), CT, KT);
+        P2N_CHECK_HIP(hipGetLastError());
+        return P2N_OK;
+    }
+    if (prec == 1) {
         const long n = (long)CT * KT * 2 * 512;
         hipLaunchKernelGGL(p2n_pack_w_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, col0, rows, k,
                            trans, reinterpret_cast<__bf16 *>(img), CT, KT);
@@ -953,7 +1209,7 @@ int pack_w(const float *W, int ldw, int col0, int rows, int k, int trans, float 
     return P2N_OK;
 }
 
-template <int MODE, bool PM, bool BF>
+template <int MODE, bool PM, int BF>   // BF: the kernel's PREC (0 fp32, 1 bf16, 2 fp32x3)
 int launch_layer_p(LayerArgs a, hipStream_t s) {
     const dim3 grid(a.Ppad / 128), blk(256);
     a.KT = (a.K + 31) / 32;
@@ -979,9 +1235,14 @@ int launch_layer_p(LayerArgs a, hipStream_t s) {
 }
 
 template <int MODE, bool PM>
-int launch_layer(LayerArgs a, hipStream_t s, bool bf = false) {
-    return bf ? launch_layer_p<MODE, PM, true>(a, s) : launch_layer_p<MODE, PM, false>(a, s);
+int launch_layer(LayerArgs a, hipStream_t s, int prec = 0) {
+    // fp32x3 needs the bf16 operand order's 16-row k-steps: any other reduction length (only the model's first layer,
+    // K = feature_dim) runs on the exact fp32 MFMA, which is the same arithmetic to fp32 accuracy
+    if (prec == 2 && a.K % 16 != 0) prec = 0;
+    return prec == 2 ? launch_layer_p<MODE, PM, 2>(a, s) : prec == 1 ? launch_layer_p<MODE, PM, 1>(a, s)
+                                                                      : launch_layer_p<MODE, PM, 0>(a, s);
 }
+int layer_prec(int prec, int K) { return (prec == 2 && K % 16 != 0) ? 0 : prec; }   // what launch_layer will run: pack accordingly
 
 int wgrad_slice(int P, int blocks) {
     // aim at ~512 workgroups (two rounds of one per CU): every workgroup ends with a block of atomics; slices are multiples of 64 points
@@ -1015,9 +1276,45 @@ int launch_wgrad_p(WgArgs a, hipStream_t s) {
     return launch_wgrad_rc<AM, BM, 1, 1, BF>(a, s);
 }
 
+template <int AM, int BM, int RT, int CT>
+int launch_wgrad_x3_rc(WgArgs a, hipStream_t s) {
+    const int ntr = (a.rows + 64 * RT - 1) / (64 * RT);
+    a.ntc = (a.cols + 64 * CT - 1) / (64 * CT);
+    a.slice = wgrad_slice(a.P, ntr * a.ntc);
+    const long nsl = ((long)a.P + a.slice - 1) / a.slice;
+    const int ps = p2n_prof_begin(P2N_K_TRAIN_WGRAD, s);
+    hipLaunchKernelGGL((p2n_wgrad_x3_kernel<AM, BM, RT, CT>), dim3(ntr * a.ntc, (unsigned)nsl), dim3(256), 0, s, a);
+    p2n_prof_end(ps, s);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
 template <int AM, int BM>
-int launch_wgrad(WgArgs a, hipStream_t s, bool bf = false) {
-    return bf ? launch_wgrad_p<AM, BM, true>(a, s) : launch_wgrad_p<AM, BM, false>(a, s);
+int launch_wgrad_x3(WgArgs a, hipStream_t s) {
+    const bool r2 = a.rows >= 128, c2 = a.cols >= 128;
+    if (r2 && c2) return launch_wgrad_x3_rc<AM, BM, 2, 2>(a, s);
+    if (r2) return launch_wgrad_x3_rc<AM, BM, 2, 1>(a, s);
+    if (c2) return launch_wgrad_x3_rc<AM, BM, 1, 2>(a, s);
+    return launch_wgrad_x3_rc<AM, BM, 1, 1>(a, s);
+}
+
+template <int AM, int BM>
+int launch_wgrad(WgArgs a, hipStream_t s, int prec = 0) {
+    if (prec == 2) return launch_wgrad_x3<AM, BM>(a, s);
+    return prec == 1 ? launch_wgrad_p<AM, BM, true>(a, s) : launch_wgrad_p<AM, BM, false>(a, s);
+}
+
+// Which GEMM families run in fp32x3 when that precision is asked for: bit 0 forward layers, bit 1 data gradients,
+// bit 2 weight gradients; the others stay on the fp32 MFMA.  Default 6: the BACKWARD's GEMMs.  The forward's fp32x3
+// form is as close to the reference's embeddings as the fp32 MFMA's (7.3e-7 vs 7.4e-7 of max on train_b4_n2048_s3) but
+// rounds differently, and the reference's sum-loss golden -- every gradient a difference of large terms in front of the
+// BatchNorms -- amplifies that to 1.1e-3 of a tensor's scale against a bar of 2e-4 (the fp32 MFMA reproduces the
+// reference's k-ascending fma chains bit for bit and sits at 1.8e-4): withdrawn from the training mode under the rule
+// "same goldens, same tolerances".  P2N_X3_MASK=7 turns it on for measurements (tools/debug_x3_train.py, bench).
+int x3_mask() {
+    static int m = -1;
+    if (m < 0) { const char *e = getenv("P2N_X3_MASK"); m = e ? (atoi(e) & 7) : 6; }
+    return m;
 }
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -1043,7 +1340,7 @@ static int check_common(const char *fn, int B, int N, int F, int E) {
 // (W,b,[gamma,beta,running_mean,running_var]) x layers; running stats are updated in place.
 // momentum < 0: eval-mode BatchNorm for a differentiable forward -- the layers normalise with the
 // running statistics, which stay untouched; p2n_train_backward on the same workspace follows suit.
-static int train_forward_run(bool bf, const float *x, int B, int N, int F, int E, const void *const *params_host,
+static int train_forward_run(int prec, const float *x, int B, int N, int F, int E, const void *const *params_host,
                              float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
                              void *workspace, size_t workspace_bytes, void *stream_) {
     TRY(check_common("p2n_train_forward", B, N, F, E));
@@ -1066,11 +1363,13 @@ static int train_forward_run(bool bf, const float *x, int B, int N, int F, int E
     // bf16 mode: the first three layers (K = 6, 64, 64: 10 % of the forward's FLOPs) stay on the fp32 MFMA -- they carry
     // the coordinates' precision, and rounding them to bf16 doubles the deviation of the embeddings (2.5e-2 -> 1.3e-2 of
     // max|emb| against the fp32 mode) for 0.05 ms; the backward runs all of its GEMMs in bf16.
+    // fp32x3 mode: every layer whose reduction length allows it (all but the first), same accuracy as fp32.
     const int bf_l0 = 3;
-    const bool bf_all = bf;
+    if (prec == 2 && !(x3_mask() & 1)) prec = 0;
+    const int prec_all = prec;
     for (int l = 0; l < 9; ++l) {
         const int K = (l == 6) ? 256 : n.cin[l];
-        bf = bf_all && l >= bf_l0;
+        const int bf = layer_prec((prec_all == 1 && l < bf_l0) ? 0 : prec_all, K);
         TRY(pack_w(n.W[l], n.cin[l], 0, n.cout[l], K, 0, n.wimg, s, bf));
         LayerArgs a = {};
         a.wimg = n.wimg; a.bias = n.b[l]; a.K = K; a.rows = n.cout[l];
@@ -1108,7 +1407,7 @@ static int train_forward_run(bool bf, const float *x, int B, int N, int F, int E
 
 // Backward of p2n_train_forward (same workspace, untouched in between).  grads_host: HOST
 // array of 34 DEVICE pointers (W,b,[gamma,beta]) x layers, each fully overwritten.
-static int train_backward_run(bool bf, const float *x, const float *gemb, int B, int N, int F, int E,
+static int train_backward_run(int bf, const float *x, const float *gemb, int B, int N, int F, int E,
                               const void *const *params_host, void *const *grads_host, void *workspace,
                               size_t workspace_bytes, void *stream_) {
     TRY(check_common("p2n_train_backward", B, N, F, E));
@@ -1132,6 +1431,8 @@ static int train_backward_run(bool bf, const float *x, const float *gemb, int B,
         }
     }
     hipStream_t s = (hipStream_t)stream_;
+    const int wprec = (bf == 2 && !(x3_mask() & 4)) ? 0 : bf;   // precision of the weight-gradient GEMMs
+    if (bf == 2 && !(x3_mask() & 2)) bf = 0;                     // ... and of the data-gradient GEMMs
     {
         // the weight gradients are accumulated with atomics and start from zero.  When all 34 gradient tensors are
         // views of one flat bucket (pointcloudsegmentation_amd/train.py hands them out that way, 256-byte aligned)
@@ -1181,8 +1482,8 @@ static int train_backward_run(bool bf, const float *x, const float *gemb, int B,
         WgArgs w = {};
         w.a0 = gemb; w.ld_a = E; w.b0 = n.z[7]; w.btab = n.ftab[7]; w.dW = dW[8];
         w.rows = E; w.cols = 128; w.ldw = 128; w.P = n.P; w.Ppad = n.Ppad;
-        TRY((launch_wgrad<LD_EMBGRAD, LD_BNRELU>(w, s, bf)));
-        TRY(pack_w(n.W[8], 128, 0, 128, E, 1, n.wimg, s, bf));
+        TRY((launch_wgrad<LD_EMBGRAD, LD_BNRELU>(w, s, wprec)));
+        TRY(pack_w(n.W[8], 128, 0, 128, E, 1, n.wimg, s, layer_prec(bf, E)));
         LayerArgs a = {};
         a.in0 = gemb; a.ld = E; a.wimg = n.wimg; a.K = E; a.rows = 128;
         a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[0];
@@ -1204,12 +1505,12 @@ static int train_backward_run(bool bf, const float *x, const float *gemb, int B,
             w.a0 = n.da[cur]; w.a1 = n.z[0]; w.atab = n.btab; w.dW = dW[0];
             w.rows = C; w.ldw = n.cin[0]; w.P = n.P; w.Ppad = n.Ppad;
             w.b0 = x; w.ld_b = F; w.cols = F;
-            TRY((launch_wgrad<LD_BNBWD, LD_X>(w, s, bf)));
+            TRY((launch_wgrad<LD_BNBWD, LD_X>(w, s, wprec)));
             break;
         }
         // data gradient first: da_{l-1} = W_l^T . dz_l, and its loader leaves dz_l in place of da_l
         const int rows = (l == 6) ? 256 : n.cin[l];
-        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, s, bf));
+        TRY(pack_w(n.W[l], n.cin[l], 0, rows, C, 1, n.wimg, s, layer_prec(bf, C)));
         LayerArgs a = {};
         a.in0 = n.da[cur]; a.in1 = n.z[l]; a.tab = n.btab; a.wimg = n.wimg; a.K = C; a.rows = rows;
         a.P = n.P; a.Ppad = n.Ppad; a.N = N; a.out = n.da[cur ^ 1]; a.dz_out = n.da[cur];
@@ -1219,7 +1520,7 @@ static int train_backward_run(bool bf, const float *x, const float *gemb, int B,
         w.a0 = n.da[cur]; w.dW = dW[l];
         w.rows = C; w.ldw = n.cin[l]; w.P = n.P; w.Ppad = n.Ppad;
         w.b0 = n.z[l - 1]; w.btab = n.ftab[l - 1]; w.cols = (l == 6) ? 256 : n.cin[l];
-        TRY((launch_wgrad<LD_PLAIN, LD_BNRELU>(w, s, bf)));
+        TRY((launch_wgrad<LD_PLAIN, LD_BNRELU>(w, s, wprec)));
         if (l == 6) {
             // global branch: per-cloud sums of dz6 -> dW6[:,256:] and dg
             StatArgs sc = st;
@@ -1245,14 +1546,14 @@ static int train_backward_run(bool bf, const float *x, const float *gemb, int B,
 extern "C" int p2n_train_forward(const float *x, int B, int N, int F, int E, const void *const *params_host,
                                  float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
                                  void *workspace, size_t workspace_bytes, void *stream_) {
-    return train_forward_run(false, x, B, N, F, E, params_host, momentum, emb, global_f, f1, f2, f3, workspace, workspace_bytes,
+    return train_forward_run(0, x, B, N, F, E, params_host, momentum, emb, global_f, f1, f2, f3, workspace, workspace_bytes,
                              stream_);
 }
 
 extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int N, int F, int E,
                                   const void *const *params_host, void *const *grads_host, void *workspace,
                                   size_t workspace_bytes, void *stream_) {
-    return train_backward_run(false, x, gemb, B, N, F, E, params_host, grads_host, workspace, workspace_bytes, stream_);
+    return train_backward_run(0, x, gemb, B, N, F, E, params_host, grads_host, workspace, workspace_bytes, stream_);
 }
 
 // The same two calls with the operands of every GEMM (layer outputs, data and weight gradients) rounded to bf16 and
@@ -1262,14 +1563,31 @@ extern "C" int p2n_train_backward(const float *x, const float *gemb, int B, int 
 extern "C" int p2n_train_forward_bf16(const float *x, int B, int N, int F, int E, const void *const *params_host,
                                       float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
                                       void *workspace, size_t workspace_bytes, void *stream_) {
-    return train_forward_run(true, x, B, N, F, E, params_host, momentum, emb, global_f, f1, f2, f3, workspace, workspace_bytes,
+    return train_forward_run(1, x, B, N, F, E, params_host, momentum, emb, global_f, f1, f2, f3, workspace, workspace_bytes,
                              stream_);
 }
 
 extern "C" int p2n_train_backward_bf16(const float *x, const float *gemb, int B, int N, int F, int E,
                                        const void *const *params_host, void *const *grads_host, void *workspace,
                                        size_t workspace_bytes, void *stream_) {
-    return train_backward_run(true, x, gemb, B, N, F, E, params_host, grads_host, workspace, workspace_bytes, stream_);
+    return train_backward_run(1, x, gemb, B, N, F, E, params_host, grads_host, workspace, workspace_bytes, stream_);
+}
+
+// The same two calls in "fp32x3" mode: every GEMM operand is split EXACTLY into three bf16 parts in the loaders (weights at
+// pack time) and the six part products of weight >= 2^-16 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the
+// fp32 mode's results to fp32 accuracy (same goldens, same tolerances: tests/test_train_x3_gpu.py) at 6/16 of its
+// matrix-pipe cycles.  Same arguments and workspace; a forward and its backward must use the same precision.
+extern "C" int p2n_train_forward_x3(const float *x, int B, int N, int F, int E, const void *const *params_host,
+                                    float momentum, float *emb, float *global_f, float *f1, float *f2, float *f3,
+                                    void *workspace, size_t workspace_bytes, void *stream_) {
+    return train_forward_run(2, x, B, N, F, E, params_host, momentum, emb, global_f, f1, f2, f3, workspace, workspace_bytes,
+                             stream_);
+}
+
+extern "C" int p2n_train_backward_x3(const float *x, const float *gemb, int B, int N, int F, int E,
+                                     const void *const *params_host, void *const *grads_host, void *workspace,
+                                     size_t workspace_bytes, void *stream_) {
+    return train_backward_run(2, x, gemb, B, N, F, E, params_host, grads_host, workspace, workspace_bytes, stream_);
 }
 
 // =========================================================================== generic shared MLP, train mode

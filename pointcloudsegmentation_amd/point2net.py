@@ -18,6 +18,12 @@ from . import params as _params
 from . import runtime as _rt
 
 
+# What a freshly constructed module computes in on GPU tensors.  "fp32": exact-fp32 MFMA (the reference's dtype).
+# "fp32x3": fp32-accurate products from exact three-way bf16 splits on the bf16 matrix pipe (same parity bar).
+# "bf16": bf16 operands, 2e-2.  tests/test_*_x3_gpu.py flip this to run the fp32 suites unchanged in fp32x3 mode.
+DEFAULT_PRECISION = "fp32"
+
+
 def _mlp(cin, cmid, cout):
     # reference point2net.py:9-16 (and :18-34): Conv1d(k=1) -> BatchNorm1d -> ReLU, twice
     return nn.Sequential(
@@ -75,7 +81,7 @@ class PointNet2Encoder(nn.Module):
         self.mlp2 = _mlp(64, 128, 128)
         self.mlp3 = _mlp(128, 256, 256)
         self.in_channels = in_channels
-        self.precision = "fp32"   # "bf16": opt-in bf16 MFMA eval path (GPU tensors only)
+        self.precision = DEFAULT_PRECISION   # "fp32" | "fp32x3" | "bf16" (GPU tensors only)
         self._cache = _PackedCache()
 
     def forward(self, x):
@@ -109,9 +115,10 @@ class Point2Net(nn.Module):
             nn.Conv1d(256 + 256, 256, 1), nn.BatchNorm1d(256), nn.ReLU(),
             nn.Conv1d(256, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
             nn.Conv1d(128, embedding_dim, 1))
-        # Not in the reference: "fp32" (default, exact-fp32 MFMA, 1e-5 parity) or "bf16" (bf16 MFMA with
-        # fp32 accumulation, 2e-2 parity, GPU eval only).  Plain attribute: not part of the state_dict.
-        self.precision = "fp32"
+        # Not in the reference: "fp32" (default, exact-fp32 MFMA, 1e-5 parity), "fp32x3" (three-way bf16 split
+        # products with fp32 accumulation on the bf16 MFMA: fp32 accuracy, same 1e-5 parity, eval and training) or
+        # "bf16" (bf16 operands, 2e-2 parity).  Plain attribute: not part of the state_dict.
+        self.precision = DEFAULT_PRECISION
         self._cache = _PackedCache()
 
     # ---- GPU paths -----------------------------------------------------

@@ -50,8 +50,9 @@ class _Point2NetTrainFn(torch.autograd.Function):
         emb = torch.empty((B, N, E), dtype=torch.float32, device=dev)
         table = _ptr_table(tensors)
         # model.precision = "bf16": GEMM operands rounded to bf16, fp32 accumulation and storage (opt-in, 2e-2)
-        ctx.bf16 = getattr(model, "precision", "fp32") == "bf16"
-        fwd = L.p2n_train_forward_bf16 if ctx.bf16 else L.p2n_train_forward
+        # "fp32x3": exact three-way bf16 splits, six part products, fp32 accumulation: fp32 accuracy on the bf16 matrix pipe
+        ctx.suffix = {"fp32": "", "bf16": "_bf16", "fp32x3": "_x3"}[getattr(model, "precision", "fp32")]
+        fwd = getattr(L, "p2n_train_forward" + ctx.suffix)
         with torch.cuda.device(dev):
             _lib.check(fwd(x.data_ptr(), B, N, F, E, table, float(momentum), emb.data_ptr(), None,
                            None, None, None, ws.data_ptr(), ws.numel(), _rt.stream_handle(dev)),
@@ -88,7 +89,7 @@ class _Point2NetTrainFn(torch.autograd.Function):
             total += (n + 63) // 64 * 64
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         grads = [flat[o:o + n].view_as(sd[k]) for o, n, k in zip(offs, sizes, learn_keys)]
-        bwd = L.p2n_train_backward_bf16 if ctx.bf16 else L.p2n_train_backward
+        bwd = getattr(L, "p2n_train_backward" + ctx.suffix)
         with torch.cuda.device(dev):
             _lib.check(bwd(ctx.x.data_ptr(), gemb.data_ptr(), B, N, F, E, _ptr_table(ctx.tensors),
                            _ptr_table(grads), ctx.ws.data_ptr(), ctx.ws.numel(),

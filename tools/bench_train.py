@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=32)
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--bf16", action="store_true", help="model.precision = 'bf16': GEMM operands in bf16 (opt-in mode)")
+    ap.add_argument("--x3", action="store_true", help="model.precision = 'fp32x3': three-way bf16 split products, fp32 accuracy")
     ap.add_argument("--no-prepare", action="store_true", help="do not start the loss's neighbour search beside the forward")
     ap.add_argument("--no-loss", action="store_true", help="loss = emb.sum() (model fwd+bwd only)")
     args = ap.parse_args()
@@ -48,6 +49,8 @@ def main():
     model = Point2Net(6, 64).to(dev).train()
     if args.bf16:
         model.precision = "bf16"
+    if args.x3:
+        model.precision = "fp32x3"
     crit = InstanceSegLoss(64, 0.1, 0.5)
     # reference train.py:84-88 (Adam, lr 1e-4, weight_decay 1e-5); fused=True is torch's single-kernel implementation of it
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
