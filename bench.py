@@ -249,6 +249,123 @@ def train_leg(device, steps=10):
     return out
 
 
+def _max_over_ranks(dist, device, seconds):
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _fence(dist, device):
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    torch.cuda.synchronize(device)
+
+
+def train_leg_dist(dist, device, rank, world, steps=10):
+    """BASELINE.json configs[3] at N > 1: the global batch of 32 x 8192 split over the ranks, parallel.train_step
+    (forward + InstanceSegLoss + backward + ONE flat gradient all-reduce over RCCL + clip + Adam) inside the timed
+    region; the all-reduce's own time from HIP events around a stand-alone repeat on the same bucket."""
+    from pointcloudsegmentation_amd import parallel
+    from pointcloudsegmentation_amd.synth import make_batch, make_labels
+    from src.models.losses import InstanceSegLoss
+    from src.models.point2net import Point2Net
+    B, N = 32, N_POINTS
+    assert B % world == 0, "the global batch of 32 clouds is split evenly over 1/2/4/8 ranks"
+    b = B // world
+    x = torch.from_numpy(make_batch(b, N, seed=200 + rank)).to(device)
+    y = torch.from_numpy(make_labels(b, N, seed=rank)).to(device)
+    out = {"workload": "train fwd + InstanceSegLoss + bwd + gradient all-reduce + clip_grad_norm_ + Adam (reference "
+                       "train.py:118-136), global B=32 x 8192 split over the ranks, random-init weights, synthetic labels",
+           "steps": steps, "clouds_per_rank": b, "scaling": "strong", "backend": dist.get_backend()}
+    for prec in ("fp32", "fp32x3"):
+        torch.manual_seed(0)                      # same initial weights on every rank
+        model = Point2Net(6, 64).to(device).train()
+        model.precision = prec
+        crit = InstanceSegLoss(64, 0.1, 0.5)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
+        for _ in range(3):
+            loss = parallel.train_step(model, crit, opt, x, y)["total_loss"]
+        _fence(dist, device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = parallel.train_step(model, crit, opt, x, y)["total_loss"]
+        _fence(dist, device)
+        ms = 1e3 * _max_over_ranks(dist, device, time.perf_counter() - t0) / steps
+        assert bool(torch.isfinite(loss))
+        # the collective alone, on the bucket the backward left behind (1.21 MB, in place)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        parallel.allreduce_gradients(model.parameters())
+        _fence(dist, device)
+        e0.record()
+        for _ in range(10):
+            parallel.allreduce_gradients(model.parameters())
+        e1.record()
+        torch.cuda.synchronize(device)
+        ar_ms = _max_over_ranks(dist, device, e0.elapsed_time(e1) / 10 * 1e-3) * 1e3
+        out[prec] = {"ms_per_step": ms, "points_per_s": B * N / (ms * 1e-3), "allreduce_ms": ar_ms,
+                     "allreduce_bytes": 4 * sum(p.numel() for p in model.parameters())}
+        del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def scenes_leg_dist(dist, device, rank, world, model):
+    """BASELINE.json configs[2]: full scenes of 40k / 80k / 150k points, host arrays in -> host labels and embeddings out
+    (normalise -> forward -> cluster, inference.predict_many), the scene list dealt round-robin over the ranks
+    (sharding.shard_indices), no collective on the data path."""
+    from pointcloudsegmentation_amd.inference import predict_many
+    from pointcloudsegmentation_amd.sharding import shard_indices
+    sizes = (40000, 80000, 150000)
+    per_rank = 6
+    n_scenes = per_rank * world
+    mine = shard_indices(n_scenes, rank, world)
+
+    def scene(i):
+        r = np.random.default_rng(500 + i)
+        n = sizes[(i // world) % len(sizes)]      # every rank gets two scenes of each size
+        return ((r.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64),
+                r.integers(0, 256, (n, 3)).astype(np.float64))
+    sc = [scene(i) for i in mine]
+    list(predict_many(model, sc[:3]))                 # allocators and pinned rings reach their steady state
+    _fence(dist, device)
+    t0 = time.perf_counter()
+    res = list(predict_many(model, sc))
+    torch.cuda.synchronize(device)
+    dt = _max_over_ranks(dist, device, time.perf_counter() - t0)
+    pts = sum(len(p) for p, _ in sc)
+    tot = torch.tensor([float(pts)], dtype=torch.float64, device=device)
+    dist.all_reduce(tot)
+    assert all(r["instance_labels"].shape[0] == len(p) for r, (p, _) in zip(res, sc))
+    return {"workload": "scene stream, 40k/80k/150k-point scenes, normalise + forward + cluster, host in -> host out "
+                        "(reference inference.py:143-188), scenes dealt round-robin over the ranks",
+            "scenes": n_scenes, "scenes_per_rank": per_rank, "seconds": dt, "scenes_per_s": n_scenes / dt,
+            "points_per_s": float(tot.item()) / dt, "scaling": "weak"}
+
+
+def lidar_leg_dist(dist, device, rank, world):
+    """BASELINE.json configs[4]: one 1M-point LiDAR-style cloud per rank: FPS to 16,384 samples, then kNN k=32 of the
+    samples in the cloud; scene-parallel (replicas, no collective)."""
+    from pointcloudsegmentation_amd import ops
+    from pointcloudsegmentation_amd.synth import make_batch
+    xyz = torch.from_numpy(np.ascontiguousarray(make_batch(1, 1_000_000, seed=40 + rank, kind="lidar")[:, :, :3])).to(device)
+    M, k = 16384, 32
+
+    def run():
+        idx = ops.farthest_point_sample(xyz, M)
+        q = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        return idx, ops.knn(q, xyz, k)[0]
+    run()
+    _fence(dist, device)
+    t0 = time.perf_counter()
+    idx, nn = run()
+    torch.cuda.synchronize(device)
+    dt = _max_over_ranks(dist, device, time.perf_counter() - t0)
+    ops.fps_check(device)
+    assert nn.shape == (1, M, k)
+    return {"workload": "1M-point cloud per rank: FPS -> 16,384 + kNN k=32 (BASELINE.json configs[4]), scene-parallel",
+            "ms_per_cloud": 1e3 * dt, "clouds_per_s": world / dt, "scaling": "weak"}
+
+
 def pmc_traffic(kernel):
     """(HBM bytes per launch, provenance) of this workload's kernel from the committed PMC summary (counters
     cannot be read from inside the process); (None, None) when the file is absent.  The provenance names the
@@ -270,6 +387,7 @@ def main():
     ap.add_argument("--no-fps", action="store_true", help="skip the FPS leg")
     ap.add_argument("--no-hier", action="store_true", help="skip the hierarchical-sibling leg")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
+    ap.add_argument("--no-scenes", action="store_true", help="skip the scene-stream leg (N > 1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -343,6 +461,17 @@ def main():
         elapsed = float(t.item())
     assert y.shape == (B_PER_GPU, N_POINTS, 64) and bool(torch.isfinite(y).all())
 
+    # N > 1: the configurations a scaling run is meant to measure besides the headline, every rank taking part
+    # (max-over-ranks timing inside each leg); the headline line's keys stay as they are
+    dist_legs = {}
+    if dist is not None:
+        if not args.no_train:
+            dist_legs["train"] = train_leg_dist(dist, device, rank, world)
+        if not args.no_scenes:
+            dist_legs["scenes"] = scenes_leg_dist(dist, device, rank, world, model)
+        if not args.no_fps:
+            dist_legs["lidar"] = lidar_leg_dist(dist, device, rank, world)
+
     if rank == 0:
         pts_step = B_PER_GPU * N_POINTS
         value = world * pts_step * args.steps / elapsed
@@ -371,6 +500,7 @@ def main():
                                  "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes "
                                  "(profiles/pmc_traffic.json), not collected live"},
         }
+        out.update(dist_legs)
         if world == 1:
             out["bf16"] = bf16_leg(model, x, lib, args.steps)
             out["fp32x3"] = x3_leg(model, x, lib, args.steps)

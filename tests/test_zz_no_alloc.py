@@ -91,3 +91,25 @@ def test_noalloc_allocates_nothing_and_rejects_oversize(ref_params):
         _lib.check(rc, "p2n_forward_eval_noalloc")
     assert L.p2n_forward_eval_noalloc(xb.data_ptr(), 0, N, 6, 64, packed.data_ptr(), eb.data_ptr(), None, None, None,
                                       None, s) == 0
+
+
+def test_noalloc_takes_its_scratch_from_the_tensors_device(ref_params):
+    """The built-in scratch is per GPU: the entry point looks the device up from x itself and refuses anything that is
+    not device memory on the current device (a host pointer here; on a multi-GPU node a tensor of another GPU gets the
+    same P2N_EINVAL instead of another GPU's scratch address)."""
+    dev = torch.device("cuda", 0)
+    L = _lib.lib()
+    packed = _packed(ref_params, dev)
+    host = torch.zeros((1, 128, 6))                      # pageable host memory: not a device pointer
+    emb = torch.empty((1, 128, 64), device=dev)
+    rc = L.p2n_forward_eval_noalloc(host.data_ptr(), 1, 128, 6, 64, packed.data_ptr(), emb.data_ptr(), None, None, None,
+                                    None, rt.stream_handle(dev))
+    assert rc != 0
+    msg = L.p2n_last_error()
+    assert b"p2n_forward_eval_noalloc" in msg or b"hipPointerGetAttributes" in msg
+    # and the call still works afterwards
+    x = torch.from_numpy(make_batch(1, 128, 3)).to(dev)
+    assert L.p2n_forward_eval_noalloc(x.data_ptr(), 1, 128, 6, 64, packed.data_ptr(), emb.data_ptr(), None, None, None,
+                                      None, rt.stream_handle(dev)) == 0
+    torch.cuda.synchronize(dev)
+    assert bool(torch.isfinite(emb).all())
