@@ -249,8 +249,18 @@ def train_leg(device, steps=10):
     return out
 
 
+def _note(msg):
+    """progress on stderr (stdout carries the one JSON line): a watcher sees which leg a long run is in"""
+    print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def _coll_device(dist, device):
+    """where the bench's own small reductions live: the GPU under RCCL, the host under gloo (rehearsal)"""
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def _max_over_ranks(dist, device, seconds):
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=_coll_device(dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -285,12 +295,14 @@ def train_leg_dist(dist, device, rank, world, steps=10):
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
         for _ in range(3):
             loss = parallel.train_step(model, crit, opt, x, y)["total_loss"]
+        _note(f"train {prec}: warm")
         _fence(dist, device)
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = parallel.train_step(model, crit, opt, x, y)["total_loss"]
         _fence(dist, device)
         ms = 1e3 * _max_over_ranks(dist, device, time.perf_counter() - t0) / steps
+        _note(f"train {prec}: {ms:.3f} ms per step")
         assert bool(torch.isfinite(loss))
         # the collective alone, on the bucket the backward left behind (1.21 MB, in place)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -333,7 +345,7 @@ def scenes_leg_dist(dist, device, rank, world, model):
     torch.cuda.synchronize(device)
     dt = _max_over_ranks(dist, device, time.perf_counter() - t0)
     pts = sum(len(p) for p, _ in sc)
-    tot = torch.tensor([float(pts)], dtype=torch.float64, device=device)
+    tot = torch.tensor([float(pts)], dtype=torch.float64, device=_coll_device(dist, device))
     dist.all_reduce(tot)
     assert all(r["instance_labels"].shape[0] == len(p) for r, (p, _) in zip(res, sc))
     return {"workload": "scene stream, 40k/80k/150k-point scenes, normalise + forward + cluster, host in -> host out "
@@ -390,6 +402,9 @@ def main():
     ap.add_argument("--no-scenes", action="store_true", help="skip the scene-stream leg (N > 1 only)")
     args = ap.parse_args()
 
+    if os.environ.get("P2N_BENCH_WATCHDOG"):      # debugging aid: dump every thread's Python stack if still running after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["P2N_BENCH_WATCHDOG"]), exit=False, file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -456,21 +471,23 @@ def main():
     kernels[DOM_KERNEL] = dom_timed[DOM_KERNEL]       # the timed region's own measurement
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = _max_over_ranks(dist, device, elapsed)
     assert y.shape == (B_PER_GPU, N_POINTS, 64) and bool(torch.isfinite(y).all())
 
     # N > 1: the configurations a scaling run is meant to measure besides the headline, every rank taking part
     # (max-over-ranks timing inside each leg); the headline line's keys stay as they are
     dist_legs = {}
     if dist is not None:
+        _note("headline done")
         if not args.no_train:
             dist_legs["train"] = train_leg_dist(dist, device, rank, world)
+            _note("train leg done")
         if not args.no_scenes:
             dist_legs["scenes"] = scenes_leg_dist(dist, device, rank, world, model)
+            _note("scenes leg done")
         if not args.no_fps:
             dist_legs["lidar"] = lidar_leg_dist(dist, device, rank, world)
+            _note("lidar leg done")
 
     if rank == 0:
         pts_step = B_PER_GPU * N_POINTS

@@ -340,12 +340,18 @@ static FpsPlan fps_plan(int B, int N) {
         // more than the distance updates it saves); otherwise ~4096 points per workgroup.
         G = gmin256;
         if (G > 1) {
-            G = (N + 4095) / 4096;
-            if (G > gmax) G = gmax;
-            // a cluster that fits one XCD (ncu/8 CUs) exchanges through that XCD's L2 (see the kernel): worth
-            // fatter workgroups when the cloud would otherwise spill over a second XCD
+            // Measured, not guessed (profiles/r02_k_fps_sweep.txt, r03_*_fps_sweep.txt): once a cloud needs a cluster at
+            // all, an iteration is the exchange plus the reduction chain, and both shrink with fewer points per thread
+            // down to ~1,024 points per workgroup -- 40,000 points: G = 10 13.6 ms, 16 13.0, 32 11.7; 150,000 points:
+            // G = 16 6.9 ms, 32 5.7, 64 (two XCDs, write-through exchange) 8.7.  So: every CU of ONE XCD that the
+            // clouds of this launch leave to a cloud (8 XCDs, clouds dealt over them), never beyond the XCD while the
+            // cloud still fits it.
             const int per_xcd = ncu / 8;
-            if (G > per_xcd && B <= 8 && (N + per_xcd - 1) / per_xcd <= FPS_LDS_POINTS && gmin256 <= per_xcd) G = per_xcd;
+            const int share = per_xcd / ((B + 7) / 8);          // CUs of an XCD per cloud when the launch's clouds are dealt over the 8 XCDs
+            G = (N + 1023) / 1024;
+            if (share >= gmin256) { if (G > share) G = share; }   // the cluster stays inside one XCD (plain-store exchange through its L2)
+            if (G > gmax) G = gmax;
+            if (G < gmin256) G = gmin256;
         }
         p.T = 256;
     } else {

@@ -18,27 +18,13 @@ import torch
 import torch.distributed as dist
 
 
-_gloo_device_ok = None    # decided once per process, by a probe every rank takes together
-
-
-def _gloo_reduces_device_tensors(device: torch.device) -> bool:
-    """gloo only: can this build all-reduce a device tensor?  One 1-element probe, entered by all ranks at the
-    same point of their first device all-reduce, so every rank takes the same path afterwards."""
-    global _gloo_device_ok
-    if _gloo_device_ok is None:
-        try:
-            dist.all_reduce(torch.zeros(1, device=device))
-            _gloo_device_ok = True
-        except RuntimeError:
-            _gloo_device_ok = False
-    return _gloo_device_ok
-
-
 def _all_reduce_mean(flat: torch.Tensor, world: int) -> None:
     """In-place mean over ranks.  Under RCCL ("nccl") the bucket is reduced where it is and any error of the
-    collective propagates (a retry on one rank only would desynchronise the job).  The host-copy path exists for
-    gloo builds without device support and is chosen by the backend, never by catching a failed collective."""
-    if flat.is_cuda and dist.get_backend() == "gloo" and not _gloo_reduces_device_tensors(flat.device):
+    collective propagates (a retry on one rank only would desynchronise the job).  Under gloo a device bucket goes
+    through a host copy -- chosen by the backend, never by catching a failed collective: gloo's own device-tensor
+    path hung after a few steps with two ranks sharing one GPU (bench.py's one-GPU rehearsal), and gloo is only ever
+    the CPU / rehearsal backend here."""
+    if flat.is_cuda and dist.get_backend() == "gloo":
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         flat.copy_(host)
