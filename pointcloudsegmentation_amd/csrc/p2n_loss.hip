@@ -995,6 +995,7 @@ extern "C" int p2n_instance_seg_loss_knn(const float *points, const float *emb, 
 // flag and the caller takes another route.
 #define DI_THREADS 1024
 #define DI_PER_THREAD 16   // labels held in registers: N <= 16384; larger clouds re-read them from memory
+#define DI_SPAN 8192        // label span (max - min + 1) the LDS histogram route covers
 
 __device__ __forceinline__ long long di_block_min(long long v, long long *sh) {
 #pragma unroll
@@ -1035,16 +1036,64 @@ __global__ __launch_bounds__(DI_THREADS) void p2n_di_peel_kernel(const long long
         for (int i = 0; i < DI_PER_THREAD; ++i) r[i] = t + i * DI_THREADS < N ? L[t + i * DI_THREADS] : NONE;
     }
     // first value: the minimum (a label equal to INT64_MAX would be taken for "none": rejected below as overflow)
-    long long cur;
+    long long cur, top;
     {
-        long long m = NONE;
+        long long m = NONE, mx = -NONE;   // (a thread without labels keeps -INT64_MAX: its negation below is representable)
         if (inreg) {
 #pragma unroll
-            for (int i = 0; i < DI_PER_THREAD; ++i) m = r[i] < m ? r[i] : m;
+            for (int i = 0; i < DI_PER_THREAD; ++i) {
+                m = r[i] < m ? r[i] : m;
+                mx = (r[i] != NONE && r[i] > mx) ? r[i] : mx;
+            }
         } else {
-            for (int i = t; i < N; i += DI_THREADS) m = L[i] < m ? L[i] : m;
+            for (int i = t; i < N; i += DI_THREADS) { const long long v = L[i]; m = v < m ? v : m; mx = (v != NONE && v > mx) ? v : mx; }
         }
         cur = di_block_min(m, shm);
+        top = -di_block_min(-mx, shm);   // an upper bound of the labels, exact unless every label is INT64_MIN
+    }
+    // Instance ids are small integers in practice (ScanNet: a few dozen per scene): when the cloud's labels span fewer
+    // than DI_SPAN values, one LDS histogram and one block scan give the ascending distinct values and their counts --
+    // the peeling loop below costs two block reductions per DISTINCT label (33 labels: ~120 us for 32 clouds) and stays
+    // as the general route (any int64 values).
+    if (cur != NONE && (unsigned long long)top - (unsigned long long)cur < (unsigned long long)DI_SPAN) {
+        __shared__ int hist[DI_SPAN];
+        __shared__ int wtot[DI_THREADS / 64];
+        for (int i = t; i < DI_SPAN; i += DI_THREADS) hist[i] = 0;
+        __syncthreads();
+        int skipped = 0;   // labels equal to INT64_MAX (the sentinel) are not counted: reported as overflow like below
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < DI_PER_THREAD; ++i)
+                if (t + i * DI_THREADS < N) { if (r[i] != NONE) atomicAdd(&hist[(int)(r[i] - cur)], 1); else ++skipped; }
+        } else {
+            for (int i = t; i < N; i += DI_THREADS) { const long long v = L[i]; if (v != NONE) atomicAdd(&hist[(int)(v - cur)], 1); else ++skipped; }
+        }
+        __syncthreads();
+        constexpr int PER = DI_SPAN / DI_THREADS;   // consecutive bins per thread
+        int nz = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) nz += hist[t * PER + i] != 0 ? 1 : 0;
+        int incl = nz;   // inclusive scan inside the wave, then over the waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((t & 63) >= o) incl += v; }
+        if ((t & 63) == 63) wtot[t >> 6] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < DI_THREADS / 64; ++w2) { before += w2 < (t >> 6) ? wtot[w2] : 0; total += wtot[w2]; }
+        int pos = before + incl - nz;
+        const int bad = __syncthreads_or(skipped != 0);
+        if (total > maxi || bad) {
+            if (t == 0) { *overflow = 1; tcount[b] = total < maxi ? total : maxi; }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = hist[t * PER + i];
+            if (c) { uniq[(long)b * maxi + pos] = cur + t * PER + i; ucnt[(long)b * maxi + pos] = c; ++pos; }
+        }
+        if (t == 0) tcount[b] = total;
+        return;
     }
     int n = 0;
     while (cur != NONE) {
