@@ -352,10 +352,21 @@ int p2n_cluster_stats(const void *workspace, long N, int D, int min_samples, uin
  * float64 or NULL (-> 0.5) -> features (N,6) float32 = [(points - mean) / max|points - mean| ,
  * colors (/255 when colors.max() > 1)], bit-identical to numpy's float64 evaluation (the row
  * sum is replayed in numpy's order).  centroid_scale (device double[4], may be NULL) receives
- * {cx, cy, cz, scale}, the reference's second and third return values. */
+ * {cx, cy, cz, scale}, the reference's second and third return values.
+ * features == NULL: statistics only -- `workspace` (8 doubles) then holds {cx, cy, cz, scale, colour flag, ...},
+ * the block p2n_forward_eval_raw takes. */
 size_t p2n_preprocess_workspace_bytes(void);
 int p2n_preprocess_points(const double *points, const double *colors, long N, float *features,
                           double *centroid_scale, void *workspace, size_t workspace_bytes, void *stream);
+/* Eval forward of ONE scene straight from the caller's float64 arrays (reference inference.py:88-103 + :172): the
+ * normalisation's affine -- subtract the centroid, divide by the scale, colours / 255 when any exceeds 1, concat,
+ * .float() -- is applied in layer 0's loader with numpy's own float64 arithmetic, so no (N,6) feature tensor is
+ * written and re-read.  prep_cs = the 8-double workspace a p2n_preprocess_points(features = NULL) call filled earlier
+ * on the same stream.  emb (N,E) / global_f (256) are bit-identical to p2n_preprocess_points + p2n_forward_eval
+ * (feature_dim 6, B = 1); workspace as p2n_forward_eval_workspace_bytes(1, N, 6, E). */
+int p2n_forward_eval_raw(const double *points, const double *colors, int N, int embedding_dim, const float *packed,
+                         const double *prep_cs, float *emb, float *global_f,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * While enabled, every kernel launch is bracketed by HIP events on its stream.

@@ -91,6 +91,7 @@ SIGNATURES = {
     "p2n_cluster_stats": (c_int, [c_vp, ctypes.c_long, c_int, c_int, c_vp, c_vp]),
     "p2n_preprocess_workspace_bytes": (c_sz, []),
     "p2n_preprocess_points": (c_int, [c_vp, c_vp, ctypes.c_long, c_f, c_vp, c_vp, c_sz, c_vp]),
+    "p2n_forward_eval_raw": (c_int, [c_vp, c_vp, c_int, c_int, c_f, c_vp, c_f, c_f, c_vp, c_sz, c_vp]),
     "p2n_profile_enable": (c_int, [c_int]),
     "p2n_profile_select": (c_int, [c_int]),
     "p2n_profile_collect": (c_int, [c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),

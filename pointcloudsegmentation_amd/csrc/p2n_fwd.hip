@@ -236,6 +236,9 @@ struct EncArgs {
     long tab;            // start of the scale/shift tables in the packed image
     int tab_n;           // floats to stage into LDS
     int scale[6], shift[6];   // offsets inside the table
+    // RAW (p2n_forward_eval_raw, one scene): layer 0 reads the scene as the caller holds it -- float64 xyz / colours --
+    // and forms the fp32 features in its loader with numpy's own float64 arithmetic (reference inference.py:88-103)
+    const double *raw_pts, *raw_col, *raw_cs;   // (N,3), (N,3) | NULL, {cx, cy, cz, scale, colours-above-1 flag}
 };
 
 // feature store in the reference's (B,C,N) layout
@@ -250,7 +253,7 @@ __device__ __forceinline__ void store_feat(float *__restrict__ f, const f32x16 v
 
 #define ENC_LDS_FLOATS (2 * CHUNK_FLOATS + 256 + P2N_TAB_MAX)
 
-template <bool FEATS>
+template <bool FEATS, bool RAW = false>
 __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
     // one LDS array: two weight chunks, [256] channel maxima, scale/shift tables
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -272,10 +275,23 @@ __global__ __launch_bounds__(256, 2) void p2n_encoder_kernel(EncArgs A) {
 
     // layer 0 operand: x[n][4h+j], zero beyond F (K padded to 8) and beyond the cloud
     f32x4 xin;
+    if (RAW) {
+        // the input normalisation's affine, fused (csrc/p2n_prep.hip: prep_write_kernel's arithmetic, bit for bit):
+        // float((p - centroid) / scale) in float64 with one rounding to float; colours / 255 when any exceeds 1, 0.5 without colours
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = 4 * h + j;
-        xin[j] = (valid && k < A.F) ? A.x[((long)b * A.N + n) * A.F + k] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * h + j;
+            float v = 0.f;
+            if (valid && k < 3) v = (float)(__dsub_rn(A.raw_pts[n * 3 + k], A.raw_cs[k]) / A.raw_cs[3]);
+            else if (valid && k < 6) v = A.raw_col ? (float)(A.raw_cs[4] > 0.0 ? A.raw_col[n * 3 + (k - 3)] / 255.0 : A.raw_col[n * 3 + (k - 3)]) : 0.5f;
+            xin[j] = v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * h + j;
+            xin[j] = (valid && k < A.F) ? A.x[((long)b * A.N + n) * A.F + k] : 0.f;
+        }
     }
 
     f32x16 a0[2];
@@ -572,13 +588,14 @@ static int allow_big_lds(K kernel, size_t bytes) {
 
 static int forward_eval_impl(const float *x, int B, int N, int F, int E, const float *packed, float *emb,
                                 float *global_f, float *f1, float *f2, float *f3, void *workspace,
-                                size_t workspace_bytes, void *stream_) {
+                                size_t workspace_bytes, void *stream_, const double *raw_pts = nullptr,
+                                const double *raw_col = nullptr, const double *raw_cs = nullptr) {
     // shared body of p2n_forward_eval and p2n_forward_eval_noalloc: launches only, no allocation
     P2N_REQUIRE(B >= 0 && N >= 0, "p2n_forward_eval: negative shape B=%d N=%d", B, N);
     P2N_REQUIRE(F >= 1 && F <= 8, "p2n_forward_eval: feature_dim %d not in [1,8]", F);
     P2N_REQUIRE(E >= 1 && E <= 256, "p2n_forward_eval: embedding_dim %d not in [1,256]", E);
     if (B == 0 || N == 0) return P2N_OK;
-    P2N_REQUIRE(x && packed, "p2n_forward_eval: null x/packed");
+    P2N_REQUIRE((x || raw_pts) && packed, "p2n_forward_eval: null x/packed");
     P2N_REQUIRE(emb || global_f || f1 || f2 || f3, "p2n_forward_eval: no output requested");
     P2N_REQUIRE((long)B * tiles_per_cloud(N) < (1L << 31), "p2n_forward_eval: B*ceil(N/128) exceeds the grid limit");
     const size_t need = p2n_forward_eval_workspace_bytes(B, N, F, E);
@@ -603,9 +620,14 @@ static int forward_eval_impl(const float *x, int B, int N, int F, int E, const f
     ea.N = N; ea.F = F; ea.tiles = tiles; ea.stream = L.enc_stream;
     ea.tab = L.scale[0]; ea.tab_n = (int)(L.scale[6] - L.scale[0]);
     for (int l = 0; l < 6; ++l) { ea.scale[l] = (int)(L.scale[l] - L.scale[0]); ea.shift[l] = (int)(L.shift[l] - L.scale[0]); }
+    ea.raw_pts = raw_pts; ea.raw_col = raw_col; ea.raw_cs = raw_cs;
     const size_t enc_lds = sizeof(float) * ENC_LDS_FLOATS;
     int ps = p2n_prof_begin(P2N_K_ENCODER, stream);
-    if (f1 || f2 || f3) {
+    if (raw_pts) {
+        int rc = allow_big_lds(p2n_encoder_kernel<false, true>, enc_lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((p2n_encoder_kernel<false, true>), dim3((unsigned)ntiles), dim3(256), enc_lds, stream, ea);
+    } else if (f1 || f2 || f3) {
         int rc = allow_big_lds(p2n_encoder_kernel<true>, enc_lds);
         if (rc) return rc;
         hipLaunchKernelGGL(p2n_encoder_kernel<true>, dim3((unsigned)ntiles), dim3(256), enc_lds, stream, ea);
@@ -646,6 +668,19 @@ extern "C" int p2n_forward_eval(const float *x, int B, int N, int F, int E, cons
                                 float *global_f, float *f1, float *f2, float *f3, void *workspace,
                                 size_t workspace_bytes, void *stream) {
     return forward_eval_impl(x, B, N, F, E, packed, emb, global_f, f1, f2, f3, workspace, workspace_bytes, stream);
+}
+
+// One scene straight from the caller's float64 arrays: reference inference.py:88-103 (subtract the centroid, divide by
+// max |.|, colours / 255 if any exceeds 1, concat, .float()) happens in layer 0's loader instead of a pass that writes an
+// (N,6) tensor for the encoder to re-read.  prep_cs = the 8-double block p2n_preprocess_points(features = NULL) filled on
+// the same stream: {cx, cy, cz, scale, colour flag, ...}.  Embeddings are bit-identical to the two-step path.
+extern "C" int p2n_forward_eval_raw(const double *points, const double *colors, int N, int E, const float *packed,
+                                    const double *prep_cs, float *emb, float *global_f, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    P2N_REQUIRE(points && prep_cs, "p2n_forward_eval_raw: null points / prep_cs");
+    P2N_REQUIRE((((uintptr_t)points | (uintptr_t)colors | (uintptr_t)prep_cs) & 7) == 0, "p2n_forward_eval_raw: float64 arrays must be 8-byte aligned");
+    return forward_eval_impl(nullptr, 1, N, 6, E, packed, emb, global_f, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream,
+                             points, colors, prep_cs);
 }
 
 // ------------------------------------------------------------------ allocation-free variant

@@ -258,7 +258,7 @@ extern "C" size_t p2n_preprocess_workspace_bytes(void) { return 8 * sizeof(doubl
 extern "C" int p2n_preprocess_points(const double *points, const double *colors, long N, float *features,
                                      double *centroid_scale, void *workspace, size_t workspace_bytes, void *stream_) {
     P2N_REQUIRE(N >= 1 && N <= (1L << 40), "p2n_preprocess_points: N=%ld must be >= 1", N);
-    P2N_REQUIRE(points && features && workspace, "p2n_preprocess_points: null pointer");
+    P2N_REQUIRE(points && workspace, "p2n_preprocess_points: null pointer");   // features == NULL: statistics only (p2n_forward_eval_raw applies them)
     if (workspace_bytes < 8 * sizeof(double)) {
         p2n_set_error("p2n_preprocess_points: workspace %zu < 64 bytes", workspace_bytes);
         return P2N_EWORKSPACE;
@@ -270,7 +270,7 @@ extern "C" int p2n_preprocess_points(const double *points, const double *colors,
     hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(1024), 0, stream, points, N, ws);
     long nb = (N * 3 + 255) / 256;
     hipLaunchKernelGGL(prep_max_kernel, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, stream, points, colors, N, ws);
-    hipLaunchKernelGGL(prep_write_kernel, dim3((unsigned)nb), dim3(256), 0, stream, points, colors, N, ws, features);
+    if (features) hipLaunchKernelGGL(prep_write_kernel, dim3((unsigned)nb), dim3(256), 0, stream, points, colors, N, ws, features);
     if (centroid_scale)
         P2N_CHECK_HIP(hipMemcpyAsync(centroid_scale, ws, 4 * sizeof(double), hipMemcpyDeviceToDevice, stream));
     p2n_prof_end(ps, stream);

@@ -9,7 +9,7 @@ import torch
 
 from . import runtime as _rt
 from .clustering import cluster_embeddings
-from .preprocess import preprocess_point_cloud
+from .preprocess import embed_scene, fused_ok, preprocess_point_cloud, preprocess_stats
 
 
 @torch.no_grad()
@@ -20,11 +20,18 @@ def predict(model, points, colors=None, eps: float = 0.1, min_samples: int = 50,
     always returns numpy)."""
     if model.training:
         raise RuntimeError("predict: call model.eval() first (reference inference.py:73)")
-    features, centroid, scale = preprocess_point_cloud(points, colors)
     dev = next(model.parameters()).device
-    if features.device != dev:
-        features = features.to(dev)
-    emb = model(features)[0]                                   # (N, D)
+    if fused_ok(model) and not (isinstance(points, torch.Tensor) and points.device != dev):
+        # the normalisation's affine runs in the encoder's layer-0 loader (p2n_forward_eval_raw): no (N,6) feature tensor
+        p, c, cs8 = preprocess_stats(points, colors)
+        emb = embed_scene(model, p, c, cs8)                    # (N, D)
+        h = cs8[:4].cpu().numpy()
+        centroid, scale = h[:3].copy(), np.float64(h[3])
+    else:
+        features, centroid, scale = preprocess_point_cloud(points, colors)
+        if features.device != dev:
+            features = features.to(dev)
+        emb = model(features)[0]                               # (N, D)
     labels = cluster_embeddings(emb, eps=eps, min_samples=min_samples)
     # reference inference.py:183: len(np.unique(labels)) - 1, whether or not a noise label occurs
     num = int(torch.unique(labels).numel()) - 1
@@ -61,6 +68,8 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
     E = model.embedding_dim
     up_ring, ring = _pinned_rings(dev, nmax, E)
 
+    fused = fused_ok(model)
+
     def stage(k):
         pts, col = scenes[k]
         p_h, c_h, last = up_ring[k % 2]
@@ -77,11 +86,14 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
             copied.record(up)
             # the normalisation rides on the upload stream too: its float64 row sum is one dependent chain on one
             # CU (numpy's order), which hides completely beside the previous scene's forward and clustering
-            feat, cs = preprocess_point_cloud(p, c, sync=False)
+            if fused:       # statistics here; the affine itself runs in the encoder's layer-0 loader on the compute stream
+                job = preprocess_stats(p, c)
+            else:
+                job = preprocess_point_cloud(p, c, sync=False)
             ev = torch.cuda.Event()
             ev.record(up)
         last[0] = copied
-        return feat, cs, ev
+        return job, ev
 
     # Results leave through a ring of three pinned slots (same cache) and are copied out into ordinary arrays when
     # yielded.
@@ -96,13 +108,17 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
     pending = None
     nxt = stage(0) if scenes else None
     for i in range(len(scenes)):
-        feat, cs, ev = nxt
+        job, ev = nxt
         main.wait_event(ev)
-        for t in (feat, cs):
-            t.record_stream(main)
+        for t in job:
+            if t is not None:
+                t.record_stream(main)
         if i + 1 < len(scenes):
             nxt = stage(i + 1)                               # upload + normalisation of scene i+1 beside the compute of scene i
-        emb = model(feat)[0]
+        if fused:
+            emb, cs = embed_scene(model, *job), job[2][:4]
+        else:
+            emb, cs = model(job[0])[0], job[1]
         labels = cluster_embeddings(emb, eps=eps, min_samples=min_samples)
         num = _count_labels(labels)
         n = labels.shape[0]
