@@ -531,6 +531,11 @@ def main():
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import bench_hier
                 out["hier"] = bench_hier.run(B_PER_GPU, N_POINTS, iters=20)
+                # the shared-MLP kernels alone on the chip (geometry in order on the same stream): their own fraction of
+                # the fp32 MFMA peak, beside the figure above where FPS / ball query / three-NN co-run on side streams
+                ser = bench_hier.run(B_PER_GPU, N_POINTS, iters=20, serial=True)
+                out["hier"]["mlp_without_corunning_geometry"] = ser["mlp"]
+                out["hier"]["ms_per_forward_wall_one_stream"] = ser["ms_per_forward_wall"]
             if not args.no_cpu:
                 port, tcpu = cpu_baselines(x_np)
                 out["cpu_baseline"] = tcpu

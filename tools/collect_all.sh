@@ -4,7 +4,7 @@
 #   tools/collect_all.sh <tag>    (run on the GPU box through gpurun)
 set -e
 tag=${1:-rXX}
-here=$(dirname "$0")
+here=$(cd "$(dirname "$0")" && pwd)
 bash $here/collect_profiles.sh $tag
 bash $here/collect_ops_profile.sh $tag
 out=$GRAFT_REPO_ROOT/gpurun_out
