@@ -39,7 +39,7 @@ sys.path.insert(0, REPO)
 
 B_PER_GPU = 16
 N_POINTS = 8192
-# algorithmic FLOPs per point (DESIGN.md "Algorithmic work"): 2 * MACs of the layers a
+# algorithmic FLOPs per point ("Roofline"): 2 * MACs of the layers a
 # kernel runs, with the global half of head layer 6 folded to a per-cloud bias
 FLOP_PER_PT = {"encoder": 2 * 127360, "head": 2 * 106496}
 FLOP_PER_PT_STEP = 467712          # SURVEY.md section 8d (598,784 as the reference writes it)
@@ -240,7 +240,7 @@ def train_leg(device, steps=10):
                      "tflops_algorithmic": 3 * FLOP_PER_PT_STEP * B * N / (ms * 1e-3) / 1e12,
                      "frac_of_fp32_mfma_peak": 3 * FLOP_PER_PT_STEP * B * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del model, opt
-    del out["bf16"]["frac_of_fp32_mfma_peak"]   # HBM-bound in this mode (DESIGN.md section 7): the fp32 MFMA peak is not its roofline
+    del out["bf16"]["frac_of_fp32_mfma_peak"]   # HBM-bound in this mode (DESIGN.md section 8): the fp32 MFMA peak is not its roofline
     del out["fp32x3"]["frac_of_fp32_mfma_peak"]   # runs on the bf16 matrix pipe: six part products per algorithmic MAC
     out["fp32x3"]["dtype"] = "f32 in/out, 3xbf16 split products (6 of 9 part products), fp32 accumulate"
     out["fp32x3"]["note"] = ("opt-in (model.precision = 'fp32x3'): same reference goldens at the same tolerances as fp32 "

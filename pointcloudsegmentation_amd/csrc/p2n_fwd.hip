@@ -106,7 +106,7 @@ __global__ void p2n_pack_kernel(const float *__restrict__ raw, float *__restrict
             if (co < L.cout[l] && k < klim) {
                 // BatchNorm's scale is folded into the weight (product in double, one rounding): the kernels start
                 // their accumulators at the shift and the epilogue is the ReLU alone -- one vector-ALU instruction
-                // per output element instead of two, and vector-ALU time adds to MFMA time
+                // per output element instead of two, and vector-ALU time adds to MFMA time (DESIGN_HISTORY section 7)
                 double w = raw[L.raw_w[l] + (long)co * L.cin[l] + k];
                 if (l < 8) w *= (double)raw[L.raw_g[l] + co] / sqrt((double)raw[L.raw_var[l] + co] + 1e-5);
                 v = (float)w;
@@ -124,7 +124,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // LDS-DMA: the destination is wave-uniform base + lane*16, i.e. the lane-linear fragment image.
 // As a buffer instruction: the stream base sits in a scalar resource, the fragment's offset is scalar arithmetic and the
 // lane offset one constant register, so staging costs no vector-ALU instruction (whose time adds to the MFMAs':
-// DESIGN section 7; written as a pointer it cost one 64-bit vector add and a readfirstlane per fragment).
+// DESIGN_HISTORY section 7; written as a pointer it cost one 64-bit vector add and a readfirstlane per fragment).
 __device__ __forceinline__ void stage_chunk(const float *__restrict__ stream, float *wbuf, int c, int wave, int lane) {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(stream), 0, -1, 0x00020000);

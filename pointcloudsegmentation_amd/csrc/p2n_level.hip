@@ -213,7 +213,7 @@ struct WStream {
         // block loop as loop invariants and spill
         asm volatile("" : "+s"(c));
         // buffer LDS-DMA: stream offset on the scalar unit, one constant lane offset -- no vector-ALU address
-        // arithmetic, whose time would add to the MFMAs' 
+        // arithmetic, whose time would add to the MFMAs' (DESIGN_HISTORY section 7)
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(stream), 0, -1, 0x00020000);
 #pragma unroll

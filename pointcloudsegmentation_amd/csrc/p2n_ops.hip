@@ -843,7 +843,7 @@ __global__ __launch_bounds__(KS_THREADS) void p2n_knn_sort_kernel(const float *_
 // running minimum keeps every minimum, hence its cached (maximum, lowest index) key.  On Morton-ordered points
 // (p2n_knn_sort_kernel: ordered copy + one box per 64-point tile) a sample reaches ~10 of the 128 buckets of an
 // 8,192-point cloud (~36 in the first 64 iterations), so the iteration is the reduction chain plus a few buckets
-// instead of 32 points per thread (0.80 -> 0.58 us per sample at 8,192 points, 1.07 -> see DESIGN at 12,288).
+// instead of 32 points per thread (0.80 -> 0.58 us per sample at 8,192 points, 1.07 -> see DESIGN_HISTORY section 4 at 12,288).
 // Layout: wave w owns buckets w, w+W, w+2W, ...; slot s of lane j is point j of bucket s*W+w (registers, as in the
 // dense kernel); lane s of the wave keeps the box and the key of the wave's slot s.  Per iteration: every lane tests its bucket's box
 // (same ((ex*ex + ey*ey) + ez*ez) roundings as a point's distance and IEEE rounding is monotonic, so the bound never

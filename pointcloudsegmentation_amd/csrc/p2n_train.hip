@@ -130,7 +130,7 @@ __device__ __forceinline__ void tl_stage(const float *__restrict__ wimg, float *
 // k4 (reduction length a multiple of 8, of 16 in bf16 mode, rows of fewer than 2^26 columns): the address of a
 // channel-major element is a wave-uniform row base (scalar registers, scalar arithmetic) plus ONE constant 32-bit lane
 // offset `voffb` -- the lane half's rows and the lane's column, in bytes -- so a tile's loads and stores need no
-// vector-ALU instruction at all.  They matter: vector-ALU time adds to MFMA time on this chip.
+// vector-ALU instruction at all.  They matter: vector-ALU time adds to MFMA time on this chip (DESIGN_HISTORY section 7).
 template <bool BF>
 __device__ __forceinline__ const float *tl_urow(const float *base, const LayerArgs &A, int kt, int g, long bbase) {
     constexpr int HR = BF ? 8 : 4;               // rows between the two lane halves

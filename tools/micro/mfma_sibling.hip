@@ -1,5 +1,5 @@
 // Micro-benchmark: what a SIMD's second wave gets done while the first one issues a block of ready, independent
-// v_mfma_f32_32x32x2_f32 (the situation of the training layer kernels at two workgroups per CU).
+// v_mfma_f32_32x32x2_f32 (the situation of the training layer kernels at two workgroups per CU, DESIGN_HISTORY §7).
 // A workgroup has 8 waves, two per SIMD.  Waves 0..3 ("matrix waves") issue MFMAs, waves 4..7 ("sibling waves") run a
 // VALU chain, L2-resident global loads, or LDS reads.  Each side is timed alone and together with the other one.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_sibling.hip -o tools/micro/mfma_sibling && tools/micro/mfma_sibling
