@@ -11,13 +11,13 @@
 
 // Tuning overrides for the sweep tools (tools/fps_sweep.py, tools/sweep_gather.sh), read from the
 // environment once per process: 0 / unset = the built-in choice.
-struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd, fps_prune, fps_pw; };
+struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd, fps_prune, fps_pw, fps_rounds; };
 static const P2nTuning &p2n_tuning() {
     static const P2nTuning t = [] {
         auto num = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
         return P2nTuning{num("P2N_FPS_G"), num("P2N_GL_CH"), num("P2N_GL_THREADS"), num("P2N_GL_SPLIT"),
                          getenv("P2N_GL_OFF") ? 1 : 0, num("P2N_FPS_T"), num("P2N_FPS_SPIN"),
-                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD"), num("P2N_FPS_PRUNE"), num("P2N_FPS_PW")};
+                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD"), num("P2N_FPS_PRUNE"), num("P2N_FPS_PW"), num("P2N_FPS_ROUNDS")};
     }();
     return t;
 }
@@ -305,6 +305,231 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
     }
 }
 
+
+// --------------------------------------------------------------------------- several samples per exchange round
+// The cluster kernel above pays one exchange (publish -> poll, two barriers) per SAMPLE.  This one pays it per ROUND
+// and lets a round accept as many samples as it can PROVE the sequential algorithm would take next, in order:
+//  * every workgroup publishes its best point (key k1 = distance bits | inverted index, coordinates) and an upper
+//    bound d2 of its second-best running minimum;
+//  * S = max d2 over the cluster.  Sort the published bests by key: c0 > c1 > ...  c0 is the next sample.  c_j is the
+//    sample after c_0..c_{j-1} if (a) dist(c_j) > S strictly -- no point that is not somebody's best can beat or tie
+//    it, and running minima only ever decrease -- and (b) none of c_0..c_{j-1} lowers c_j's own running minimum, i.e.
+//    !(|c_i - c_j|^2 < dist(c_j)) in the very arithmetic of the update.  Then c_j still holds its published distance,
+//    every best with a smaller key is still below it in key order (= the tie rule), and every other point is <= S.
+//    The round stops at the first c_j that fails; that point simply stays its workgroup's best for the next round.
+//  * every workgroup takes the same decision from the same records, applies the accepted samples to its running
+//    minima and starts the next round.  Indices are those of the sequential algorithm bit for bit (tools/
+//    sim_fps_rounds.py is the CPU model: 5.5 samples per round at 40,000 points with 32 workgroups).
+// Records live in a ring of FR_RING rounds; every 8-byte granule carries the round number as its tag, so nothing is
+// cleared between rounds (a workgroup can be at most one round ahead of the slowest: it cannot publish round r+1
+// before it has read everybody's round r).
+#define FR_RING 4
+#define FR_SLOT 8      // u64 per record: six tagged granules {k1 hi, k1 lo, x, y, z, d2}, padded to 64 bytes
+#define FR_MAXW 64
+
+template <int PPT>
+__global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
+    constexpr int T = 256;
+    static_assert(PPT % 2 == 0, "points are processed in pairs");
+    extern __shared__ __attribute__((aligned(16))) float lxyz[];
+    __shared__ unsigned wv[4][4];                                     // per wave: best distance bits, inverted index, second best
+    __shared__ __attribute__((aligned(16))) float wl[2][FR_MAXW][4];  // the samples a round accepted
+    __shared__ int nwl[2];
+    __shared__ int verdict_s;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    __builtin_amdgcn_s_setprio(3);
+    int cl, g;
+    if (A.xcd_mode) {
+        const int r = blockIdx.x & 7, q = blockIdx.x >> 3;
+        cl = (q / A.G) * 8 + r;
+        if (cl >= A.nb) return;
+        g = q % A.G;
+    } else {
+        cl = blockIdx.x / A.G; g = blockIdx.x % A.G;
+    }
+    const int b = A.b0 + cl;
+    const float *P = A.xyz + (long)b * A.N * 3;
+    const int base = g * A.chunk;
+    int nloc = A.N - base;
+    if (nloc > A.chunk) nloc = A.chunk;
+    if (nloc < 0) nloc = 0;
+    u64 *ring = A.slots + (long)cl * (FR_RING + 1) * A.G * FR_SLOT;   // [FR_RING + 1][G][FR_SLOT]; the last row is the XCD census
+
+    f32x2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], md[PPT / 2];
+    for (int i = t; i < nloc * 3; i += T) lxyz[i] = P[(long)base * 3 + i];
+    if (t < 4) wl[0][0][t] = t < 3 ? P[(long)A.start_idx * 3 + t] : 0.f;
+    if (t == 0) nwl[0] = 1;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int i = t + T * s;
+        const bool ok = i < nloc;
+        const float *src = lxyz + i * 3;
+        px[s / 2][s & 1] = ok ? src[0] : 0.f;
+        py[s / 2][s & 1] = ok ? src[1] : 0.f;
+        pz[s / 2][s & 1] = ok ? src[2] : 0.f;
+        md[s / 2][s & 1] = ok ? __int_as_float(0x7f800000) : 0.f;
+    }
+    bool dead = false, census_dead = false, fast = false;
+    if (A.xcd_mode) {   // XCD census, as in the kernel above
+        if (wave == 0) {
+            u64 *cs = ring + (long)FR_RING * A.G * FR_SLOT;
+            const unsigned myx = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 0xF;
+            if (lane == 0) __hip_atomic_store(cs + g * FR_SLOT, (1ull << 32) | (u64)myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64 v = 1ull << 32 | myx;
+            int spins = 0;
+            bool ok;
+            for (;;) {
+                if (lane < A.G) v = __hip_atomic_load(cs + lane * FR_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = __all(lane >= A.G || v != 0ull);
+                if (ok || ++spins > A.spin_limit) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool same = __all(lane >= A.G || (unsigned)v == myx);
+            if (lane == 0) verdict_s = ok ? (same ? 1 : 0) : -1;
+        }
+        __syncthreads();
+        const int verdict = verdict_s;
+        fast = verdict == 1;
+        if (verdict < 0) dead = census_dead = true;
+    }
+    if (g == 0 && t == 0) A.idx[(long)b * A.M] = A.start_idx;
+    const unsigned inv0 = 0xFFFFFFFFu - (unsigned)(base + t);
+    int it = 1, nw = 1, buf = 0;
+    unsigned round = 0;
+    while (!dead && it < A.M) {
+        // ---- apply the samples of the last round to the running minima
+        for (int j = 0; j < nw; ++j) {
+            const float4 c = *reinterpret_cast<const float4 *>(&wl[buf][j][0]);
+            const f32x2 c2x = {c.x, c.x}, c2y = {c.y, c.y}, c2z = {c.z, c.z};
+#pragma unroll
+            for (int p = 0; p < PPT / 2; ++p) {
+                const f32x2 dx = px[p] - c2x, dy = py[p] - c2y, dz = pz[p] - c2z;
+                const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+                float m0, m1;
+                asm("v_min_f32 %0, %1, %2" : "=v"(m0) : "v"(md[p][0]), "v"(dd[0]));
+                asm("v_min_f32 %0, %1, %2" : "=v"(m1) : "v"(md[p][1]), "v"(dd[1]));
+                md[p][0] = m0;
+                md[p][1] = m1;
+            }
+        }
+        ++round;
+        // ---- this thread's best (tournament of 64-bit keys) and the largest of its other running minima
+        u64 tk[PPT / 2];
+#pragma unroll
+        for (int p = 0; p < PPT / 2; ++p) {
+            const bool take = md[p][1] > md[p][0];
+            tk[p] = ((u64)__float_as_uint(take ? md[p][1] : md[p][0]) << 32) | (unsigned)(take ? 62 - 2 * p : 63 - 2 * p);
+        }
+#pragma unroll
+        for (int w = 1; w < PPT / 2; w <<= 1)
+#pragma unroll
+            for (int p = 0; p < PPT / 2; ++p)
+                if (p % (2 * w) == 0 && p + w < PPT / 2) tk[p] = tk[p + w] > tk[p] ? tk[p + w] : tk[p];
+        const unsigned bcode = (unsigned)(tk[0] & 0xFFFFFFFFull);
+        unsigned sec = 0u;
+#pragma unroll
+        for (int p = 0; p < PPT / 2; ++p) {
+            const unsigned v0 = bcode == (unsigned)(63 - 2 * p) ? 0u : __float_as_uint(md[p][0]);
+            const unsigned v1 = bcode == (unsigned)(62 - 2 * p) ? 0u : __float_as_uint(md[p][1]);
+            const unsigned v = v0 > v1 ? v0 : v1;
+            sec = sec > v ? sec : v;
+        }
+        const unsigned hi = (unsigned)(tk[0] >> 32);
+        const unsigned lo = inv0 - (unsigned)(T * (63 - (int)bcode));
+        // ---- wave: best key, and the second best = max over lanes of (the winner lane's second, everybody else's best)
+        const unsigned whi = wave_max_u32(hi);
+        const unsigned wlo = wave_max_u32(hi == whi ? lo : 0u);
+        const unsigned wsec = wave_max_u32((hi == whi && lo == wlo) ? sec : hi);
+        if (lane == 0) { wv[wave][0] = whi; wv[wave][1] = wlo; wv[wave][2] = wsec; }
+        __syncthreads();
+        if (wave == 0) {
+            const int nbuf = buf ^ 1;
+            // workgroup: the same combination over the four waves
+            const unsigned h4 = lane < 4 ? wv[lane][0] : 0u, l4 = lane < 4 ? wv[lane][1] : 0u, s4 = lane < 4 ? wv[lane][2] : 0u;
+            const unsigned k1hi = wave_max_u32(h4);
+            const unsigned k1lo = wave_max_u32(h4 == k1hi ? l4 : 0u);
+            const unsigned d2 = wave_max_u32((lane < 4 && h4 == k1hi && l4 == k1lo) ? s4 : h4);
+            const int li = (int)(0xFFFFFFFFu - k1lo);
+            u64 *slot = ring + (long)(round % FR_RING) * A.G * FR_SLOT;
+            if (lane < 6 && !(A.fault_it > 0 && it == A.fault_it + 1 && g == A.G - 1)) {
+                const bool real = li >= base && li < base + nloc;   // a workgroup without real points publishes zeros with its losing key
+                unsigned pay = lane == 0 ? k1hi : lane == 1 ? k1lo : d2;
+                if (lane >= 2 && lane < 5) pay = real ? __float_as_uint(lxyz[(li - base) * 3 + lane - 2]) : 0u;
+                const u64 gran = ((u64)round << 32) | (u64)pay;
+                u64 *dst = slot + g * FR_SLOT + lane;
+                if (fast) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(gran) : "memory");
+                else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0}, rc = {0, 0, 0, 0};
+            const bool mine = lane < A.G;
+            int spins = 0;
+            bool ok;
+            for (;;) {
+                bool ready = true;
+                if (mine) {
+                    const u64 *sl = slot + lane * FR_SLOT;
+                    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+                                 "s_waitcnt vmcnt(0)"
+                                 : "=&v"(ra), "=&v"(rb), "=&v"(rc) : "v"(sl) : "memory");
+                    ready = ra[1] == round && ra[3] == round && rb[1] == round && rb[3] == round && rc[1] == round && rc[3] == round;
+                }
+                ok = __all(ready);
+                if (ok || ++spins > A.spin_limit) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned khi = mine ? ra[0] : 0u, klo = mine ? ra[2] : 0u;
+            const float x = __uint_as_float(rb[0]), y = __uint_as_float(rb[2]), z = __uint_as_float(rc[0]);
+            const unsigned S = wave_max_u32(mine ? rc[2] : 0u);
+            const unsigned ahi = wave_max_u32(khi);
+            const unsigned alo = wave_max_u32(khi == ahi ? klo : 0u);
+            const bool cand = mine && (khi > S || (khi == ahi && klo == alo));
+            u64 cm = __ballot(cand);
+            unsigned rank = 0u;
+            bool aff = false;
+            const float mydist = __uint_as_float(khi);
+            while (cm) {
+                const int i = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                const unsigned ohi = (unsigned)__builtin_amdgcn_readlane((int)khi, i), olo = (unsigned)__builtin_amdgcn_readlane((int)klo, i);
+                const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+                const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), i));
+                const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), i));
+                const bool bigger = ohi > khi || (ohi == khi && olo > klo);
+                rank += bigger ? 1u : 0u;
+                const float dd = sqdist3(x, y, z, ox, oy, oz);   // the update's own expression: would candidate i lower my minimum?
+                aff = aff || (bigger && dd < mydist);
+            }
+            const unsigned rblk = (cand && aff) ? rank : 64u;
+            const int rstar = 64 - (int)wave_max_u32(64u - rblk);   // rank of the first candidate an earlier one would change
+            int limit = rstar < A.M - it ? rstar : A.M - it;
+            if (A.fault_it > 0 && it <= A.fault_it && limit > A.fault_it + 1 - it) limit = A.fault_it + 1 - it;   // test hook: a round boundary at the faulted sample
+            const bool acc = cand && (int)rank < limit;
+            const int widx = (int)(0xFFFFFFFFu - klo);
+            int m = (int)__builtin_popcountll(__ballot(acc));
+            if (!ok || m < 1 || __any(acc && (widx < 0 || widx >= A.N))) m = -1;
+            if (acc && m > 0) {
+                wl[nbuf][rank][0] = x; wl[nbuf][rank][1] = y; wl[nbuf][rank][2] = z; wl[nbuf][rank][3] = 0.f;
+                if (g == 0) A.idx[(long)b * A.M + it + (int)rank] = widx;
+            }
+            if (lane == 0) nwl[nbuf] = m;
+        }
+        __syncthreads();
+        buf ^= 1;
+        nw = nwl[buf];
+        if (nw < 0) { dead = true; break; }
+        it += nw;
+    }
+    if (dead) {
+        if (t == 0) atomicExch(A.status, 1);
+        if (g == 0)
+            for (int i = (census_dead ? 0 : it) + t; i < A.M; i += T) A.idx[(long)b * A.M + i] = A.start_idx;
+    }
+}
+
 // bucket-pruned single-workgroup variant (defined behind the Morton sort it builds on)
 static size_t fps_pruned_bytes(int B, int N, int M);
 static int fps_pruned_run(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, void *scratch, hipStream_t s);
@@ -384,12 +609,19 @@ static FpsPlan fps_plan(int B, int N) {
     return p;
 }
 
+// exchange slots of B clouds at the largest cluster (64 workgroups): per-iteration slots of the one-sample kernel or
+// the record ring of the rounds kernel, whichever is larger
+static size_t fps_slot_bytes(int B, int M) {
+    const size_t a = sizeof(u64) * 4 * (size_t)(M + 1) * 64, r = sizeof(u64) * FR_SLOT * (size_t)(FR_RING + 1) * 64;
+    return (size_t)B * (a > r ? a : r);
+}
+
 extern "C" size_t p2n_fps_workspace_bytes(int B, int N, int M) {
     if (B < 1 || N < 1 || M < 1) return 16;
     // slots of the largest sub-batch: at most 64 workgroups per cloud, 32 bytes each per sample
     const FpsPlan p = fps_plan(1, N);
     const int gmax = p.G > 1 ? 64 : 1;
-    return 256 + (gmax > 1 ? sizeof(u64) * 4 * (size_t)B * (M + 1) * gmax : 0) + fps_pruned_bytes(B, N, M);
+    return 256 + (gmax > 1 ? fps_slot_bytes(B, M) : 0) + fps_pruned_bytes(B, N, M);
 }
 
 template <int T, int PPT, bool LDSXYZ>
@@ -403,6 +635,21 @@ static hipError_t fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
     const int ps = p2n_prof_begin(P2N_K_FPS, s);
     const unsigned grid = a.xcd_mode ? 8u * a.G * ((nb + 7) / 8) : (unsigned)(nb * a.G);
     hipLaunchKernelGGL((p2n_fps_kernel<T, PPT, LDSXYZ>), dim3(grid), dim3(T), lds, s, a);
+    p2n_prof_end(ps, s);
+    return hipGetLastError();
+}
+
+template <int PPT>
+static hipError_t fps_rounds_launch(const FpsArgs &a, int nb, hipStream_t s) {
+    const size_t lds = (size_t)a.chunk * 12;
+    if (lds > 32 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_fps_rounds_kernel<PPT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int ps = p2n_prof_begin(P2N_K_FPS, s);
+    const unsigned grid = a.xcd_mode ? 8u * a.G * ((nb + 7) / 8) : (unsigned)(nb * a.G);
+    hipLaunchKernelGGL((p2n_fps_rounds_kernel<PPT>), dim3(grid), dim3(256), lds, s, a);
     p2n_prof_end(ps, s);
     return hipGetLastError();
 }
@@ -440,7 +687,7 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
     if (!status) P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));   // no private status word: the workspace's
     if (fps_pruned_bytes(B, N, M)) {   // one workgroup per cloud, no exchange: nothing can time out, the status stays as it is
         const FpsPlan p1 = fps_plan(1, N);
-        const size_t off = 256 + (p1.G > 1 ? sizeof(u64) * 4 * (size_t)B * (M + 1) * 64 : 0);
+        const size_t off = 256 + (p1.G > 1 ? fps_slot_bytes(B, M) : 0);
         return fps_pruned_run(xyz, B, N, M, start_idx, idx, (char *)workspace + off, stream);
     }
     // sub-batches so that every launch's workgroups are co-resident (<= 256)
@@ -463,10 +710,23 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         a.xcd_mode = p.G > 1 && p.G * ((nb + 7) / 8) <= ncu / 8 && !p2n_tuning().fps_noxcd;
         a.slots = (u64 *)((char *)workspace + 256);
         a.N = N; a.M = M; a.G = p.G; a.chunk = (N + p.G - 1) / p.G; a.start_idx = start_idx; a.b0 = done;
+        const bool rounds = p.G > 1 && p.T == 256 && p2n_tuning().fps_rounds >= 0;   // P2N_FPS_ROUNDS=-1: one sample per exchange (A/B)
         if (p.G > 1)   // launches run in stream order, so they can share the slot region
-            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 256, 0, sizeof(u64) * 4 * (size_t)nb * (M + 1) * p.G, stream));
+            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 256, 0, rounds ? sizeof(u64) * FR_SLOT * (size_t)nb * (FR_RING + 1) * p.G
+                                                                            : sizeof(u64) * 4 * (size_t)nb * (M + 1) * p.G, stream));
         hipError_t e = hipErrorInvalidValue;
-        if (p.T == 256) {
+        if (rounds) {
+            switch (p.ppt) {
+                case 2: e = fps_rounds_launch<2>(a, nb, stream); break;
+                case 4: e = fps_rounds_launch<4>(a, nb, stream); break;
+                case 8: e = fps_rounds_launch<8>(a, nb, stream); break;
+                case 16: e = fps_rounds_launch<16>(a, nb, stream); break;
+                case 24: e = fps_rounds_launch<24>(a, nb, stream); break;
+                case 32: e = fps_rounds_launch<32>(a, nb, stream); break;
+                case 40: e = fps_rounds_launch<40>(a, nb, stream); break;
+                case 48: e = fps_rounds_launch<48>(a, nb, stream); break;
+            }
+        } else if (p.T == 256) {
             switch (p.ppt) {
                 case 2: e = fps_launch<256, 2, true>(a, nb, stream); break;
                 case 4: e = fps_launch<256, 4, true>(a, nb, stream); break;
