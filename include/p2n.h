@@ -226,11 +226,17 @@ int p2n_combine3(const float *g3, const float *a, const float *b, const float *c
  * ties). ----------------------------------------------------------------- */
 
 /* Farthest-point sampling: xyz (B,N,3) -> idx (B,M); first sample = start_idx.
- * Clouds beyond 12,288 points are sampled by a cluster of workgroups that exchange their winners through
- * memory every iteration (p2n_fps_workgroups_per_cloud > 1) and must all be resident at once; if another
- * kernel keeps them from it, the bounded wait of an exchange runs out: the kernel then stores 1 into
- * *status (device int32, never cleared by the library, so one word can collect many calls; NULL = word 0 of
- * the workspace, cleared by every call) and fills the rest of the cloud's idx row with start_idx. */
+ * Clouds of 4,096 points and more are sampled by a CLUSTER -- single waves (4,096..100,000 points, up to 64 per
+ * cloud, kind 1) or 256/1024-thread workgroups (larger clouds, kind 2) -- whose members keep the cloud in registers and
+ * exchange records through memory: one exchange per ROUND, and a round accepts every published best that provably is
+ * the sequential algorithm's next sample (indices are bit-identical to the one-at-a-time algorithm).  The members of
+ * a cluster must all be resident at once (p2n_fps_workgroups_per_cloud > 1); if another kernel keeps them from it, the
+ * bounded wait of an exchange runs out: the kernel then stores 1 into *status (device int32, never cleared by the
+ * library, so one word can collect many calls; NULL = word 0 of the workspace, cleared by every call) and fills the
+ * rest of the cloud's idx row with start_idx.  p2n_fps_cluster_kind: 0 = one workgroup per cloud (cannot fail),
+ * 1 = wave members (a few registers and 1-8 KB of LDS each: they fit beside other kernels), 2 = workgroup members
+ * (planned as if they owned every compute unit: run them alone). */
+int p2n_fps_cluster_kind(int B, int N);
 size_t p2n_fps_workspace_bytes(int B, int N, int M);
 int p2n_fps_workgroups_per_cloud(int B, int N);
 int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int32_t *idx, int32_t *status,

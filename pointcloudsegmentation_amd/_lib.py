@@ -46,6 +46,7 @@ SIGNATURES = {
     "p2n_forward_eval_x3": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
     "p2n_fps_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "p2n_fps_workgroups_per_cloud": (c_int, [c_int, c_int]),
+    "p2n_fps_cluster_kind": (c_int, [c_int, c_int]),
     "p2n_fps": (c_int, [c_f, c_int, c_int, c_int, c_int, c_i, c_i, c_vp, c_sz, c_vp]),
     "p2n_ball_query": (c_int, [c_f, c_f, c_int, c_int, c_int, c_float, c_int, c_i, c_vp]),
     "p2n_knn": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_i, c_f, c_vp]),

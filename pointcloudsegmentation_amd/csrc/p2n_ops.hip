@@ -11,13 +11,13 @@
 
 // Tuning overrides for the sweep tools (tools/fps_sweep.py, tools/sweep_gather.sh), read from the
 // environment once per process: 0 / unset = the built-in choice.
-struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd, fps_prune, fps_pw, fps_rounds; };
+struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd, fps_prune, fps_pw, fps_rounds, fps_pd; };
 static const P2nTuning &p2n_tuning() {
     static const P2nTuning t = [] {
         auto num = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
         return P2nTuning{num("P2N_FPS_G"), num("P2N_GL_CH"), num("P2N_GL_THREADS"), num("P2N_GL_SPLIT"),
                          getenv("P2N_GL_OFF") ? 1 : 0, num("P2N_FPS_T"), num("P2N_FPS_SPIN"),
-                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD"), num("P2N_FPS_PRUNE"), num("P2N_FPS_PW"), num("P2N_FPS_ROUNDS")};
+                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD"), num("P2N_FPS_PRUNE"), num("P2N_FPS_PW"), num("P2N_FPS_ROUNDS"), num("P2N_FPS_PD")};
     }();
     return t;
 }
@@ -96,6 +96,7 @@ struct FpsArgs {
     int *status;        // set to 1 when an exchange timed out (never cleared here)
     int N, M, G, chunk, start_idx, b0, spin_limit;
     int xcd_mode, nb;   // xcd_mode: grid = 8*G*ceil(nb/8) blocks, a cloud's workgroups share blockIdx % 8 (one XCD under round-robin dealing)
+    int poll_delay;     // s_sleep units between a round's publish and its first poll (rounds kernels)
     int fault_it;       // test hook (P2N_FPS_FAULT=k): the cloud's last workgroup skips its publish in iteration k; 0 = off
 };
 
@@ -314,18 +315,128 @@ __global__ __launch_bounds__(T) void p2n_fps_kernel(FpsArgs A) {
 //  * S = max d2 over the cluster.  Sort the published bests by key: c0 > c1 > ...  c0 is the next sample.  c_j is the
 //    sample after c_0..c_{j-1} if (a) dist(c_j) > S strictly -- no point that is not somebody's best can beat or tie
 //    it, and running minima only ever decrease -- and (b) none of c_0..c_{j-1} lowers c_j's own running minimum, i.e.
-//    !(|c_i - c_j|^2 < dist(c_j)) in the very arithmetic of the update.  Then c_j still holds its published distance,
+//    !(|c_i - c_j|^2 < dist(c_j)) in the very arithmetic of the update (and every c_i has finite coordinates, so that
+//    its own running minimum dropped to 0 when it was taken).  Then c_j still holds its published distance,
 //    every best with a smaller key is still below it in key order (= the tie rule), and every other point is <= S.
 //    The round stops at the first c_j that fails; that point simply stays its workgroup's best for the next round.
 //  * every workgroup takes the same decision from the same records, applies the accepted samples to its running
 //    minima and starts the next round.  Indices are those of the sequential algorithm bit for bit (tools/
 //    sim_fps_rounds.py is the CPU model: 5.5 samples per round at 40,000 points with 32 workgroups).
-// Records live in a ring of FR_RING rounds; every 8-byte granule carries the round number as its tag, so nothing is
-// cleared between rounds (a workgroup can be at most one round ahead of the slowest: it cannot publish round r+1
+// Records live in a ring of FR_RING rounds; every 8-byte granule carries the round number (16 bits, never 0) as its tag, so
+// nothing is cleared between rounds (a workgroup can be at most one round ahead of the slowest: it cannot publish round r+1
 // before it has read everybody's round r).
 #define FR_RING 4
-#define FR_SLOT 8      // u64 per record: six tagged granules {k1 hi, k1 lo, x, y, z, d2}, padded to 64 bytes
+#define FR_SLOT 4      // u64 per record: four granules, each {payload word, tag16 << 16 | half of k1 lo / d2}: 32 bytes, so that one
+                       // 128-byte line holds four records (every member polls every record: the L2 request count is what a poll costs)
 #define FR_MAXW 64
+
+
+typedef unsigned fr_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned fr_tag(unsigned round) { return (round % 65535u) + 1u; }
+// lanes 0..3 of the publishing wave store one granule each
+__device__ __forceinline__ void fr_publish(u64 *rec, int lane, unsigned tag, unsigned k1hi, unsigned k1lo, unsigned x, unsigned y,
+                                           unsigned z, unsigned d2, bool fast) {
+    const unsigned lo = lane == 0 ? k1hi : lane == 1 ? x : lane == 2 ? y : z;
+    const unsigned half = lane == 0 ? (k1lo & 0xFFFFu) : lane == 1 ? (k1lo >> 16) : lane == 2 ? (d2 & 0xFFFFu) : (d2 >> 16);
+    const u64 gran = ((u64)((tag << 16) | half) << 32) | (u64)lo;
+    u64 *dst = rec + lane;
+    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(gran) : "memory");   // same XCD: plain store, served from the shared L2
+    else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one poll of one record (L1 bypassed); true when all four granules carry this round's tag
+__device__ __forceinline__ bool fr_poll(const u64 *rec, unsigned tag, fr_u32x4 &a, fr_u32x4 &c) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(c) : "v"(rec) : "memory");
+    const unsigned T = tag << 16;
+    return (((a[1] ^ T) | (a[3] ^ T) | (c[1] ^ T) | (c[3] ^ T)) >> 16) == 0u;
+}
+
+// The round's decision, taken by one wave from the records it polled (lane = cluster member): which published bests are
+// the next samples, in which order.  Candidates = bests above every member's second best (S); when there are at most
+// 16 of them -- the usual case -- they are compacted into LDS and all candidate pairs are evaluated at once (lane =
+// (candidate i = lane & 15, other candidate j = lane >> 4 + 4 * pass): is j earlier in key order, and would accepting j
+// lower i's running minimum?); ballots turn the pair results into every candidate's rank and "blocked" flag.  The result
+// lives in candidate space (lane p < n holds candidate p's record).  More than 16 candidates take the serial walk over
+// the candidate mask in member space.  Either way: acc lanes hold an accepted sample's coordinates, rank and index.
+struct FrDecision { bool acc; unsigned rank; unsigned klo; float x, y, z; };
+__device__ __forceinline__ FrDecision fr_decide(const bool mine, const unsigned khi, const unsigned klo, const float x, const float y,
+                                                const float z, const unsigned d2v, const int room, float4 *rec, u64 *reck,
+                                                const int lane) {
+    FrDecision D;
+    const unsigned S = wave_max_u32(mine ? d2v : 0u);
+    bool cand = mine && khi > S;
+    u64 cmask = __ballot(cand);
+    if (cmask == 0ull) {   // the largest distance ties somebody's second best: only the overall best is provably next
+        const unsigned ahi = wave_max_u32(mine ? khi : 0u);
+        const unsigned alo = wave_max_u32(mine && khi == ahi ? klo : 0u);
+        cand = mine && khi == ahi && klo == alo;
+        cmask = __ballot(cand);
+    }
+    const int n = (int)__builtin_popcountll(cmask);
+    unsigned rank = 0u;
+    bool blocked = false, candp;
+    if (n <= 16) {
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cmask, 0u));
+        if (cand) { rec[pos] = make_float4(x, y, z, __uint_as_float(khi)); reck[pos] = ((u64)khi << 32) | klo; }
+        // one wave writes and reads: LDS serves a wave's instructions in order, so only the compiler has to be told
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int i = lane & 15, jb = lane >> 4;
+        // all reads first (entries past n are stale and masked below), so that their latencies overlap
+        const float4 Ri = rec[i];
+        const u64 ki = reck[i];
+        float4 Rj[4];
+        u64 kj[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) { Rj[pass] = rec[jb + 4 * pass]; kj[pass] = reck[jb + 4 * pass]; }
+        const u64 col = 0x0001000100010001ull << i;
+        const unsigned colo = (unsigned)col, cohi = (unsigned)(col >> 32);
+        const bool iv = i < n;
+        u64 many = 0ull;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            if (4 * pass < n) {   // uniform
+                const bool bigger = iv && jb + 4 * pass < n && kj[pass] > ki;
+                const float dd = sqdist3(Ri.x, Ri.y, Ri.z, Rj[pass].x, Rj[pass].y, Rj[pass].z);   // the update's own expression
+                // a sample with a non-finite coordinate never clears its own running minimum (p - p is NaN): the
+                // sequential algorithm picks it again at once, so nothing may follow it within a round
+                const bool sticky = !__builtin_isfinite((Rj[pass].x + Rj[pass].y) + Rj[pass].z);
+                const u64 mb = __ballot(bigger);
+                many |= __ballot(bigger && (dd < Ri.w || sticky));
+                rank += (unsigned)__builtin_popcount((unsigned)mb & colo) + (unsigned)__builtin_popcount((unsigned)(mb >> 32) & cohi);
+            }
+        }
+        blocked = (many & col) != 0ull;
+        candp = lane < n;
+        D.x = Ri.x; D.y = Ri.y; D.z = Ri.z; D.klo = (unsigned)ki;
+    } else {
+        u64 cm = cmask;
+        const float mydist = __uint_as_float(khi);
+        while (cm) {
+            const int i = __builtin_ctzll(cm);
+            cm &= cm - 1;
+            const unsigned ohi = (unsigned)__builtin_amdgcn_readlane((int)khi, i), olo = (unsigned)__builtin_amdgcn_readlane((int)klo, i);
+            const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+            const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), i));
+            const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), i));
+            const bool bigger = ohi > khi || (ohi == khi && olo > klo);
+            rank += bigger ? 1u : 0u;
+            const float dd = sqdist3(x, y, z, ox, oy, oz);
+            blocked = blocked || (bigger && (dd < mydist || !__builtin_isfinite((ox + oy) + oz)));
+        }
+        candp = cand;
+        D.x = x; D.y = y; D.z = z; D.klo = klo;
+    }
+    const unsigned rblk = (candp && blocked) ? rank : 64u;
+    const int rstar = 64 - (int)wave_max_u32(64u - rblk);   // rank of the first candidate an earlier one would change
+    const int limit = rstar < room ? rstar : room;
+    D.acc = candp && (int)rank < limit;
+    D.rank = rank;
+    return D;
+}
 
 template <int PPT>
 __global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
@@ -336,6 +447,8 @@ __global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
     __shared__ __attribute__((aligned(16))) float wl[2][FR_MAXW][4];  // the samples a round accepted
     __shared__ int nwl[2];
     __shared__ int verdict_s;
+    __shared__ float4 rec[16];
+    __shared__ u64 reck[16];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     __builtin_amdgcn_s_setprio(3);
     int cl, g;
@@ -452,68 +565,35 @@ __global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
             const unsigned d2 = wave_max_u32((lane < 4 && h4 == k1hi && l4 == k1lo) ? s4 : h4);
             const int li = (int)(0xFFFFFFFFu - k1lo);
             u64 *slot = ring + (long)(round % FR_RING) * A.G * FR_SLOT;
-            if (lane < 6 && !(A.fault_it > 0 && it == A.fault_it + 1 && g == A.G - 1)) {
+            const unsigned tag = fr_tag(round);
+            if (lane < 4 && !(A.fault_it > 0 && it == A.fault_it + 1 && g == A.G - 1)) {
                 const bool real = li >= base && li < base + nloc;   // a workgroup without real points publishes zeros with its losing key
-                unsigned pay = lane == 0 ? k1hi : lane == 1 ? k1lo : d2;
-                if (lane >= 2 && lane < 5) pay = real ? __float_as_uint(lxyz[(li - base) * 3 + lane - 2]) : 0u;
-                const u64 gran = ((u64)round << 32) | (u64)pay;
-                u64 *dst = slot + g * FR_SLOT + lane;
-                if (fast) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(gran) : "memory");
-                else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned cxb = real ? __float_as_uint(lxyz[(li - base) * 3 + 0]) : 0u, cyb = real ? __float_as_uint(lxyz[(li - base) * 3 + 1]) : 0u,
+                               czb = real ? __float_as_uint(lxyz[(li - base) * 3 + 2]) : 0u;
+                fr_publish(slot + g * FR_SLOT, lane, tag, k1hi, k1lo, cxb, cyb, czb, d2, fast);
             }
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0}, rc = {0, 0, 0, 0};
+            fr_u32x4 ra = {0, 0, 0, 0}, rc = {0, 0, 0, 0};
             const bool mine = lane < A.G;
             int spins = 0;
-            bool ok;
+            bool ok, ready = !mine;
+            for (int d = 0; d < A.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             for (;;) {
-                bool ready = true;
-                if (mine) {
-                    const u64 *sl = slot + lane * FR_SLOT;
-                    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
-                                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
-                                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
-                                 "s_waitcnt vmcnt(0)"
-                                 : "=&v"(ra), "=&v"(rb), "=&v"(rc) : "v"(sl) : "memory");
-                    ready = ra[1] == round && ra[3] == round && rb[1] == round && rb[3] == round && rc[1] == round && rc[3] == round;
-                }
+                if (!ready) ready = fr_poll(slot + lane * FR_SLOT, tag, ra, rc);
                 ok = __all(ready);
                 if (ok || ++spins > A.spin_limit) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            const unsigned khi = mine ? ra[0] : 0u, klo = mine ? ra[2] : 0u;
-            const float x = __uint_as_float(rb[0]), y = __uint_as_float(rb[2]), z = __uint_as_float(rc[0]);
-            const unsigned S = wave_max_u32(mine ? rc[2] : 0u);
-            const unsigned ahi = wave_max_u32(khi);
-            const unsigned alo = wave_max_u32(khi == ahi ? klo : 0u);
-            const bool cand = mine && (khi > S || (khi == ahi && klo == alo));
-            u64 cm = __ballot(cand);
-            unsigned rank = 0u;
-            bool aff = false;
-            const float mydist = __uint_as_float(khi);
-            while (cm) {
-                const int i = __builtin_ctzll(cm);
-                cm &= cm - 1;
-                const unsigned ohi = (unsigned)__builtin_amdgcn_readlane((int)khi, i), olo = (unsigned)__builtin_amdgcn_readlane((int)klo, i);
-                const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
-                const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), i));
-                const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), i));
-                const bool bigger = ohi > khi || (ohi == khi && olo > klo);
-                rank += bigger ? 1u : 0u;
-                const float dd = sqdist3(x, y, z, ox, oy, oz);   // the update's own expression: would candidate i lower my minimum?
-                aff = aff || (bigger && dd < mydist);
-            }
-            const unsigned rblk = (cand && aff) ? rank : 64u;
-            const int rstar = 64 - (int)wave_max_u32(64u - rblk);   // rank of the first candidate an earlier one would change
-            int limit = rstar < A.M - it ? rstar : A.M - it;
-            if (A.fault_it > 0 && it <= A.fault_it && limit > A.fault_it + 1 - it) limit = A.fault_it + 1 - it;   // test hook: a round boundary at the faulted sample
-            const bool acc = cand && (int)rank < limit;
-            const int widx = (int)(0xFFFFFFFFu - klo);
-            int m = (int)__builtin_popcountll(__ballot(acc));
-            if (!ok || m < 1 || __any(acc && (widx < 0 || widx >= A.N))) m = -1;
-            if (acc && m > 0) {
-                wl[nbuf][rank][0] = x; wl[nbuf][rank][1] = y; wl[nbuf][rank][2] = z; wl[nbuf][rank][3] = 0.f;
-                if (g == 0) A.idx[(long)b * A.M + it + (int)rank] = widx;
+            const unsigned khi = mine ? ra[0] : 0u, klo = mine ? ((ra[1] & 0xFFFFu) | (ra[3] << 16)) : 0u;
+            int room = A.M - it;
+            if (A.fault_it > 0 && it <= A.fault_it && room > A.fault_it + 1 - it) room = A.fault_it + 1 - it;   // test hook: a round boundary at the faulted sample
+            const FrDecision D = fr_decide(mine, khi, klo, __uint_as_float(ra[2]), __uint_as_float(rc[0]), __uint_as_float(rc[2]),
+                                           (rc[1] & 0xFFFFu) | (rc[3] << 16), room, rec, reck, lane);
+            const int widx = (int)(0xFFFFFFFFu - D.klo);
+            int m = (int)__builtin_popcountll(__ballot(D.acc));
+            if (!ok || m < 1 || __any(D.acc && (widx < 0 || widx >= A.N))) m = -1;
+            if (D.acc && m > 0) {
+                wl[nbuf][D.rank][0] = D.x; wl[nbuf][D.rank][1] = D.y; wl[nbuf][D.rank][2] = D.z; wl[nbuf][D.rank][3] = 0.f;
+                if (g == 0) A.idx[(long)b * A.M + it + (int)D.rank] = widx;
             }
             if (lane == 0) nwl[nbuf] = m;
         }
@@ -528,6 +608,221 @@ __global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
         if (g == 0)
             for (int i = (census_dead ? 0 : it) + t; i < A.M; i += T) A.idx[(long)b * A.M + i] = A.start_idx;
     }
+}
+
+
+
+#ifdef P2N_FPS_TIMING   // phase clocks of member 0 of cloud 0 (development aid: make HIPFLAGS+=-DP2N_FPS_TIMING)
+#define FR_T_DECL long long frt_[6] = {0, 0, 0, 0, 0, 0}, frs_[6] = {0, 0, 0, 0, 0, 0}; int frn_ = 0
+#define FR_T(i) do { frt_[i] = (long long)__builtin_readcyclecounter(); if ((i) > 0) frs_[i] += frt_[i] - frt_[(i) - 1]; if ((i) == 5) ++frn_; } while (0)
+#define FR_T_DUMP do { if (g == 0 && cl == 0 && lane == 0) printf("fps rounds=%d samples=%d  cycles per round: update %lld reduce %lld publish %lld poll %lld decide %lld\n", frn_, it, frs_[1] / (frn_ ? frn_ : 1), frs_[2] / (frn_ ? frn_ : 1), frs_[3] / (frn_ ? frn_ : 1), frs_[4] / (frn_ ? frn_ : 1), frs_[5] / (frn_ ? frn_ : 1)); } while (0)
+#else
+#define FR_T_DECL
+#define FR_T(i)
+#define FR_T_DUMP
+#endif
+// --------------------------------------------------------------------------- the same rounds with ONE WAVE per member
+// A cluster member is a single wave (a 64-thread workgroup): no barrier, no LDS hand-over inside a round -- the wave
+// updates its points, reduces, publishes, polls, decides and keeps the accepted samples in the registers it polled them
+// into.  Up to 64 members per cloud (one decision lane each), placed on one XCD, one per SIMD.  More members mean
+// more candidates per round (tools/sim_fps_rounds.py: 7 samples per round at 64 members) and fewer points per lane.
+template <int PPT>
+__global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {
+    constexpr int T = 64;
+    static_assert(PPT % 2 == 0, "points are processed in pairs");
+    extern __shared__ __attribute__((aligned(16))) float lxyz[];
+    __shared__ float4 rec[16];
+    __shared__ u64 reck[16];
+    const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    int cl, g;
+    if (A.xcd_mode) {
+        const int r = blockIdx.x & 7, q = blockIdx.x >> 3;
+        cl = (q / A.G) * 8 + r;
+        if (cl >= A.nb) return;
+        g = q % A.G;
+    } else {
+        cl = blockIdx.x / A.G; g = blockIdx.x % A.G;
+    }
+    const int b = A.b0 + cl;
+    const float *P = A.xyz + (long)b * A.N * 3;
+    const int base = g * A.chunk;
+    int nloc = A.N - base;
+    if (nloc > A.chunk) nloc = A.chunk;
+    if (nloc < 0) nloc = 0;
+    u64 *ring = A.slots + (long)cl * (FR_RING + 1) * A.G * FR_SLOT;
+
+    f32x2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], md[PPT / 2];
+    for (int i = lane; i < nloc * 3; i += T) lxyz[i] = P[(long)base * 3 + i];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int i = lane + T * s;
+        const bool ok = i < nloc;
+        const float *src = lxyz + i * 3;
+        px[s / 2][s & 1] = ok ? src[0] : 0.f;
+        py[s / 2][s & 1] = ok ? src[1] : 0.f;
+        pz[s / 2][s & 1] = ok ? src[2] : 0.f;
+        md[s / 2][s & 1] = ok ? __int_as_float(0x7f800000) : 0.f;
+    }
+    bool dead = false, census_dead = false, fast = false;
+    if (A.xcd_mode) {
+        u64 *cs = ring + (long)FR_RING * A.G * FR_SLOT;
+        const unsigned myx = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 0xF;
+        if (lane == 0) __hip_atomic_store(cs + g * FR_SLOT, (1ull << 32) | (u64)myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 v = 1ull << 32 | myx;
+        int spins = 0;
+        bool ok;
+        for (;;) {
+            if (lane < A.G) v = __hip_atomic_load(cs + lane * FR_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = __all(lane >= A.G || v != 0ull);
+            if (ok || ++spins > A.spin_limit) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        fast = ok && __all(lane >= A.G || (unsigned)v == myx);
+        if (!ok) dead = census_dead = true;
+    }
+    if (g == 0 && lane == 0) A.idx[(long)b * A.M] = A.start_idx;
+    const unsigned inv0 = 0xFFFFFFFFu - (unsigned)(base + lane);
+    // the accepted samples of the last round: coordinates in the lanes named by `am` (first round: the start point)
+    float x = P[(long)A.start_idx * 3 + 0], y = P[(long)A.start_idx * 3 + 1], z = P[(long)A.start_idx * 3 + 2];
+    u64 am = 1ull;
+    int it = 1;
+    unsigned round = 0;
+    FR_T_DECL;
+    while (!dead && it < A.M) {
+        FR_T(0);
+        while (am) {
+            const int i = __builtin_ctzll(am);
+            am &= am - 1;
+            const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+            const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), i));
+            const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), i));
+            const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+            for (int p = 0; p < PPT / 2; ++p) {
+                const f32x2 dx = px[p] - c2x, dy = py[p] - c2y, dz = pz[p] - c2z;
+                const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+                float m0, m1;
+                asm("v_min_f32 %0, %1, %2" : "=v"(m0) : "v"(md[p][0]), "v"(dd[0]));
+                asm("v_min_f32 %0, %1, %2" : "=v"(m1) : "v"(md[p][1]), "v"(dd[1]));
+                md[p][0] = m0;
+                md[p][1] = m1;
+            }
+        }
+        ++round;
+        FR_T(1);
+        u64 tk[PPT / 2];
+#pragma unroll
+        for (int p = 0; p < PPT / 2; ++p) {
+            const bool take = md[p][1] > md[p][0];
+            tk[p] = ((u64)__float_as_uint(take ? md[p][1] : md[p][0]) << 32) | (unsigned)(take ? 62 - 2 * p : 63 - 2 * p);
+        }
+#pragma unroll
+        for (int w = 1; w < PPT / 2; w <<= 1)
+#pragma unroll
+            for (int p = 0; p < PPT / 2; ++p)
+                if (p % (2 * w) == 0 && p + w < PPT / 2) tk[p] = tk[p + w] > tk[p] ? tk[p + w] : tk[p];
+        const unsigned bcode = (unsigned)(tk[0] & 0xFFFFFFFFull);
+        unsigned sec = 0u;
+#pragma unroll
+        for (int p = 0; p < PPT / 2; ++p) {
+            const unsigned v0 = bcode == (unsigned)(63 - 2 * p) ? 0u : __float_as_uint(md[p][0]);
+            const unsigned v1 = bcode == (unsigned)(62 - 2 * p) ? 0u : __float_as_uint(md[p][1]);
+            const unsigned v = v0 > v1 ? v0 : v1;
+            sec = sec > v ? sec : v;
+        }
+        const unsigned hi = (unsigned)(tk[0] >> 32);
+        const unsigned lo = inv0 - (unsigned)(T * (63 - (int)bcode));
+        const unsigned k1hi = wave_max_u32(hi);
+        const unsigned k1lo = wave_max_u32(hi == k1hi ? lo : 0u);
+        const unsigned d2 = wave_max_u32((hi == k1hi && lo == k1lo) ? sec : hi);
+        FR_T(2);
+        const int li = (int)(0xFFFFFFFFu - k1lo);
+        u64 *slot = ring + (long)(round % FR_RING) * A.G * FR_SLOT;
+        const unsigned tag = fr_tag(round);
+        if (lane < 4 && !(A.fault_it > 0 && it == A.fault_it + 1 && g == A.G - 1)) {
+            const bool real = li >= base && li < base + nloc;
+            const unsigned cxb = real ? __float_as_uint(lxyz[(li - base) * 3 + 0]) : 0u, cyb = real ? __float_as_uint(lxyz[(li - base) * 3 + 1]) : 0u,
+                           czb = real ? __float_as_uint(lxyz[(li - base) * 3 + 2]) : 0u;
+            fr_publish(slot + g * FR_SLOT, lane, tag, k1hi, k1lo, cxb, cyb, czb, d2, fast);
+        }
+        FR_T(3);
+        fr_u32x4 ra = {0, 0, 0, 0}, rc = {0, 0, 0, 0};
+        const bool mine = lane < A.G;
+        int spins = 0;
+        bool ok, ready = !mine;
+        for (int d = 0; d < A.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+        for (;;) {
+            if (!ready) ready = fr_poll(slot + lane * FR_SLOT, tag, ra, rc);
+            ok = __all(ready);
+            if (ok || ++spins > A.spin_limit) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        FR_T(4);
+        const unsigned khi = mine ? ra[0] : 0u, klo = mine ? ((ra[1] & 0xFFFFu) | (ra[3] << 16)) : 0u;
+        int room = A.M - it;
+        if (A.fault_it > 0 && it <= A.fault_it && room > A.fault_it + 1 - it) room = A.fault_it + 1 - it;
+        const FrDecision D = fr_decide(mine, khi, klo, __uint_as_float(ra[2]), __uint_as_float(rc[0]), __uint_as_float(rc[2]),
+                                       (rc[1] & 0xFFFFu) | (rc[3] << 16), room, rec, reck, lane);
+        x = D.x; y = D.y; z = D.z;
+        const int widx = (int)(0xFFFFFFFFu - D.klo);
+        am = __ballot(D.acc);
+        const int m = (int)__builtin_popcountll(am);
+        if (!ok || m < 1 || __any(D.acc && (widx < 0 || widx >= A.N))) { dead = true; break; }
+        if (D.acc && g == 0) A.idx[(long)b * A.M + it + (int)D.rank] = widx;
+        it += m;
+        FR_T(5);
+    }
+    FR_T_DUMP;
+    if (dead) {
+        if (lane == 0) atomicExch(A.status, 1);
+        if (g == 0)
+            for (int i = (census_dead ? 0 : it) + lane; i < A.M; i += T) A.idx[(long)b * A.M + i] = A.start_idx;
+    }
+}
+
+static int fps_cus();
+static const int kFpsPptW[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48};
+struct FpsWavePlan { int G, ppt; };
+// members (single waves) per cloud when nb clouds share the launch: one XCD per cloud, at most one member per SIMD
+static FpsWavePlan fps_wave_plan(int nb, int N) {
+    FpsWavePlan w = {0, 0};
+    const int ncu = fps_cus();
+    const int cap = (ncu / 8) * 4, per = (nb + 7) / 8;
+    int G = cap / per;
+    if (G > 64) G = 64;
+    if (const int g = p2n_tuning().fps_g) { if (g >= 2 && g <= G) G = g; }
+    while (G > 2 && (N + G - 1) / G < 64) G >>= 1;   // at least one point per lane
+    if (G < 2) return w;
+    const int chunk = (N + G - 1) / G, need = (chunk + 63) / 64;
+    for (int i = 0; i < 12; ++i)
+        if (kFpsPptW[i] >= need) { w.ppt = kFpsPptW[i]; break; }
+    if (w.ppt == 0 || (size_t)chunk * 12 > 64 * 1024) return w;
+    w.G = G;
+    return w;
+}
+
+// which clouds take the wave clusters (P2N_FPS_ROUNDS: 2 = always where a plan exists, 1 / -1 = never)
+static bool fps_wave_rounds_wanted(int B, int N) {
+    const int mode = p2n_tuning().fps_rounds;
+    if (mode == 1 || mode < 0) return false;
+    const FpsWavePlan w = fps_wave_plan(B < 64 ? B : 64, N);
+    if (w.G < 2) return false;
+    if (mode == 2) return true;
+    // measured (profiles/r03_h_fps_rounds_ab*.txt): below ~4,096 points one workgroup without any exchange is as fast;
+    // beyond ~100,000 a member's 1,500+ points per wave make the update the round, and 256-thread members win
+    return N >= 4096 && N <= 100000 && w.G >= 8;
+}
+
+template <int PPT>
+static hipError_t fps_wave_launch(const FpsArgs &a, int nb, hipStream_t s) {
+    const size_t lds = (size_t)a.chunk * 12;
+    const int ps = p2n_prof_begin(P2N_K_FPS, s);
+    const unsigned grid = a.xcd_mode ? 8u * a.G * ((nb + 7) / 8) : (unsigned)(nb * a.G);
+    hipLaunchKernelGGL((p2n_fps_wave_rounds_kernel<PPT>), dim3(grid), dim3(64), lds, s, a);
+    p2n_prof_end(ps, s);
+    return hipGetLastError();
 }
 
 // bucket-pruned single-workgroup variant (defined behind the Morton sort it builds on)
@@ -611,8 +906,8 @@ static FpsPlan fps_plan(int B, int N) {
 
 // exchange slots of B clouds at the largest cluster (64 workgroups): per-iteration slots of the one-sample kernel or
 // the record ring of the rounds kernel, whichever is larger
-static size_t fps_slot_bytes(int B, int M) {
-    const size_t a = sizeof(u64) * 4 * (size_t)(M + 1) * 64, r = sizeof(u64) * FR_SLOT * (size_t)(FR_RING + 1) * 64;
+static size_t fps_slot_bytes(int B, int M, bool one_sample_kernel) {
+    const size_t a = one_sample_kernel ? sizeof(u64) * 4 * (size_t)(M + 1) * 64 : 0, r = sizeof(u64) * FR_SLOT * (size_t)(FR_RING + 1) * 64;
     return (size_t)B * (a > r ? a : r);
 }
 
@@ -621,7 +916,7 @@ extern "C" size_t p2n_fps_workspace_bytes(int B, int N, int M) {
     // slots of the largest sub-batch: at most 64 workgroups per cloud, 32 bytes each per sample
     const FpsPlan p = fps_plan(1, N);
     const int gmax = p.G > 1 ? 64 : 1;
-    return 256 + (gmax > 1 ? fps_slot_bytes(B, M) : 0) + fps_pruned_bytes(B, N, M);
+    return 256 + fps_slot_bytes(B, M, gmax > 1) + fps_pruned_bytes(B, N, M);
 }
 
 template <int T, int PPT, bool LDSXYZ>
@@ -654,7 +949,14 @@ static hipError_t fps_rounds_launch(const FpsArgs &a, int nb, hipStream_t s) {
     return hipGetLastError();
 }
 
+extern "C" int p2n_fps_cluster_kind(int B, int N) {
+    if (B < 1 || N < 1) return 0;
+    if (fps_wave_rounds_wanted(B, N)) return 1;
+    return p2n_fps_workgroups_per_cloud(B, N) > 1 ? 2 : 0;
+}
+
 extern "C" int p2n_fps_workgroups_per_cloud(int B, int N) {
+    if (B >= 1 && N >= 1 && fps_wave_rounds_wanted(B, N)) return fps_wave_plan(B < 64 ? B : 64, N).G;
     // the LARGEST cluster p2n_fps(B, N, ...) will actually launch: the same sub-batching and halving as below, so a
     // cloud that only fits with fewer clouds in flight (B = 64 x 100,000 points) reports its clusters, not 0
     if (B < 1 || N < 1) return 0;
@@ -685,15 +987,47 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         return P2N_EWORKSPACE;
     }
     if (!status) P2N_CHECK_HIP(hipMemsetAsync(workspace, 0, 16, stream));   // no private status word: the workspace's
+    const int spin = p2n_tuning().fps_spin > 0 ? p2n_tuning().fps_spin : FPS_SPIN_LIMIT;
+    if (fps_wave_rounds_wanted(B, N)) {
+        int done = 0;
+        while (done < B) {
+            const int nb = B - done < 64 ? B - done : 64;
+            const FpsWavePlan w = fps_wave_plan(nb, N);
+            P2N_REQUIRE(w.G >= 2, "p2n_fps: no wave-cluster plan for N=%d", N);
+            FpsArgs a;
+            a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault; a.poll_delay = p2n_tuning().fps_pd;
+            a.nb = nb; a.xcd_mode = !p2n_tuning().fps_noxcd && fps_cus() % 8 == 0;
+            a.slots = (u64 *)((char *)workspace + 256);
+            a.N = N; a.M = M; a.G = w.G; a.chunk = (N + w.G - 1) / w.G; a.start_idx = start_idx; a.b0 = done;
+            P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 256, 0, sizeof(u64) * FR_SLOT * (size_t)nb * (FR_RING + 1) * w.G, stream));
+            hipError_t e = hipErrorInvalidValue;
+            switch (w.ppt) {
+                case 2: e = fps_wave_launch<2>(a, nb, stream); break;
+                case 4: e = fps_wave_launch<4>(a, nb, stream); break;
+                case 6: e = fps_wave_launch<6>(a, nb, stream); break;
+                case 8: e = fps_wave_launch<8>(a, nb, stream); break;
+                case 10: e = fps_wave_launch<10>(a, nb, stream); break;
+                case 12: e = fps_wave_launch<12>(a, nb, stream); break;
+                case 16: e = fps_wave_launch<16>(a, nb, stream); break;
+                case 20: e = fps_wave_launch<20>(a, nb, stream); break;
+                case 24: e = fps_wave_launch<24>(a, nb, stream); break;
+                case 32: e = fps_wave_launch<32>(a, nb, stream); break;
+                case 40: e = fps_wave_launch<40>(a, nb, stream); break;
+                case 48: e = fps_wave_launch<48>(a, nb, stream); break;
+            }
+            P2N_CHECK_HIP(e);
+            done += nb;
+        }
+        return P2N_OK;
+    }
     if (fps_pruned_bytes(B, N, M)) {   // one workgroup per cloud, no exchange: nothing can time out, the status stays as it is
         const FpsPlan p1 = fps_plan(1, N);
-        const size_t off = 256 + (p1.G > 1 ? fps_slot_bytes(B, M) : 0);
+        const size_t off = 256 + fps_slot_bytes(B, M, p1.G > 1);
         return fps_pruned_run(xyz, B, N, M, start_idx, idx, (char *)workspace + off, stream);
     }
     // sub-batches so that every launch's workgroups are co-resident (<= 256)
     int done = 0;
     const int ncu = fps_cus();
-    const int spin = p2n_tuning().fps_spin > 0 ? p2n_tuning().fps_spin : FPS_SPIN_LIMIT;
     while (done < B) {
         int nb = B - done;
         if (nb > ncu) nb = ncu;
@@ -704,7 +1038,7 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         }
         P2N_REQUIRE(p.G >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 64 * 1024 * 20);
         FpsArgs a;
-        a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault;
+        a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault; a.poll_delay = p2n_tuning().fps_pd;
         a.nb = nb;
         // one XCD per cloud when its cluster and the other clouds sharing that XCD fit the XCD's 32 CUs
         a.xcd_mode = p.G > 1 && p.G * ((nb + 7) / 8) <= ncu / 8 && !p2n_tuning().fps_noxcd;

@@ -65,8 +65,15 @@ def farthest_point_sample(xyz: torch.Tensor, npoint: int, start_idx: int = 0) ->
 
 
 def fps_needs_check(B: int, N: int) -> bool:
-    """True when clouds of this size are sampled by several workgroups each (the only way FPS can fail)."""
+    """True when clouds of this size are sampled by a cluster of waves or workgroups (the only way FPS can fail)."""
     return _lib.lib().p2n_fps_workgroups_per_cloud(max(B, 1), max(N, 1)) > 1
+
+
+def fps_needs_whole_chip(B: int, N: int) -> bool:
+    """True when the clouds are sampled by clusters of fat workgroups, planned as if they owned every compute unit:
+    run such a call alone (no kernels of other streams beside it).  Wave-member clusters (4,096..100,000 points) are
+    light enough to become resident beside other kernels."""
+    return _lib.lib().p2n_fps_cluster_kind(max(B, 1), max(N, 1)) == 2
 
 
 def fps_status(device) -> int:

@@ -533,11 +533,13 @@ class Point2NetSA(nn.Module):
         dev = x.device
         main = torch.cuda.current_stream(dev)
         xyz0 = x[:, :, :3].contiguous()
-        # Clouds sampled by workgroup CLUSTERS (> 12,288 points) are planned as if they owned every CU: beside the level
-        # kernels of other streams their workgroups may not all be resident and the exchange would time out.  They run
-        # the whole forward in order on the caller's stream instead (no overlap, nothing to time out against).
+        # Clouds sampled by clusters of fat WORKGROUPS (> 100,000 points) are planned as if they owned every CU: beside the
+        # level kernels of other streams their workgroups may not all be resident and the exchange would time out.  They
+        # run the whole forward in order on the caller's stream instead (no overlap, nothing to time out against).
+        # Wave-member clusters (4,096..100,000 points) are a few registers and an LDS sliver per member: they fit beside
+        # the level kernels and keep the overlap; either kind is checked where the indices have been consumed.
         clusters = ops.fps_needs_check(x.shape[0], x.shape[1])
-        if not self.overlap_geometry or clusters:
+        if not self.overlap_geometry or ops.fps_needs_whole_chip(x.shape[0], x.shape[1]):
             xyz1, f1 = self.sa1.forward_rows(xyz0, x, F, 3, c)                     # level 1 reads x's rows in place
             xyz2, f2 = self.sa2.forward_rows(xyz1, f1, f1.shape[2], 0, f1.shape[2])
             xyz3, f3 = self.sa3.forward_rows(xyz2, f2, f2.shape[2], 0, f2.shape[2])
@@ -629,7 +631,7 @@ class Point2NetSA(nn.Module):
         for x in batches:
             if x.dim() != 3 or x.size(2) != self.feature_dim:
                 raise ValueError(f"expected batches of shape (B, N, {self.feature_dim}), got {tuple(x.shape)}")
-        if any(ops.fps_needs_check(x.shape[0], x.shape[1]) for x in batches):
+        if any(ops.fps_needs_whole_chip(x.shape[0], x.shape[1]) for x in batches):
             return [self._forward_fused(x) for x in batches]   # workgroup clusters must own the chip: no pipelining
         dev = x0.device
         main = torch.cuda.current_stream(dev)
@@ -646,6 +648,8 @@ class Point2NetSA(nn.Module):
             j = i + GEO_LANES
             if j < len(xs):
                 geo[j] = self._geometry(xyz0[j], start, j % GEO_LANES)
+        if any(ops.fps_needs_check(x.shape[0], x.shape[1]) for x in xs):
+            ops.fps_check(dev)       # wave clusters sampled these clouds: one check (and synchronisation) for the whole sequence
         return out
 
 

@@ -122,44 +122,26 @@ def test_fps_ties_duplicates_and_oversampling():
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("case", ["lattice", "duplicates", "blobs", "flat", "ragged", "oversample", "nan"])
-def test_fps_bucket_pruned_kernel_edge_cases(case):
-    """Clouds of 5,120..12,288 points take the bucket-pruned single-workgroup kernel (Morton-ordered copy, per-bucket
-    skip test): same indices as the oracle on exact ties, duplicates, degenerate extents, ragged tile counts, more
-    samples than distinct points, and a NaN coordinate."""
-    from oracle import oracle
-    from pointcloudsegmentation_amd import ops
-    rng = np.random.default_rng(11)
-    M, start = 300, 5
-    if case == "lattice":
-        xyz = _grid_cloud(2, 18)                                   # 5,832 lattice points: masses of exact ties
-    elif case == "duplicates":
-        base = _cloud(1, 1000, seed=3)
-        xyz = np.concatenate([base] * 7, axis=1)                   # every point seven times
-        xyz = xyz[:, rng.permutation(xyz.shape[1])]
-        M = 1200                                                   # beyond the 1,000 distinct points: all-zero distances, lowest index
-    elif case == "blobs":
-        c = rng.standard_normal((1, 12, 3)).astype(np.float32) * 3
-        xyz = (c[:, rng.integers(0, 12, 9000)] + 0.01 * rng.standard_normal((1, 9000, 3))).astype(np.float32)
-    elif case == "flat":
-        xyz = _cloud(2, 6000, seed=8)
-        xyz[:, :, 2] = 0.25                                        # zero extent in z
-        xyz[1, :, 1] = -1.0                                        # a line
-    elif case == "ragged":
-        xyz = _cloud(3, 12288 - 37, seed=9)                        # last tile partly filled, 192 buckets
-        M, start = 500, 12250
-    elif case == "oversample":
-        xyz = _cloud(1, 5120, seed=10)
-        M = 5120                                                   # every point is selected exactly once
-    else:
-        xyz = _cloud(1, 7000, seed=12)
-        xyz[0, 4321, 1] = np.nan
-        M = 64
-    want = oracle.fps(xyz, M, start)
-    got = ops.farthest_point_sample(torch.from_numpy(np.ascontiguousarray(xyz)).cuda(), M, start).cpu().numpy()
-    np.testing.assert_array_equal(got, want)
-    if case == "oversample":
-        assert sorted(got[0].tolist()) == list(range(5120))
+def test_fps_edge_cases_default_routing():
+    """Exact ties (lattices), duplicates, degenerate extents, ragged member sizes, more samples than distinct points, a NaN
+    coordinate, 1..N samples, more clouds than one launch takes: same indices as the oracle (tests/fps_cases.py), with the
+    kernels the library picks by itself (wave clusters for 4,096..100,000 points, 256-thread round clusters above)."""
+    import fps_cases
+    fps_cases.run(small=False)
+
+
+@pytest.mark.parametrize("mode", ["2", "1", "-1"])
+def test_fps_edge_cases_forced_kernel_family(mode):
+    """The same cases with one kernel family forced (read once per process, hence a child): 2 = wave clusters on every
+    shape that has a plan (down to 5 points), 1 = 256-thread round clusters + the single-workgroup kernels (dense and
+    bucket-pruned), -1 = the one-sample-per-exchange cluster kernel."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fps_cases.py")], env=dict(os.environ, P2N_FPS_ROUNDS=mode),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_fps_errors():
@@ -473,9 +455,9 @@ def test_sa_group_variants(B, C, N, M, ns):
 
 
 def test_fps_exchange_timeout_is_loud_and_indices_stay_in_range():
-    """The multi-workgroup FPS needs all workgroups of a cloud resident at once.  When an exchange
-    times out (forced here: P2N_FPS_FAULT makes one workgroup skip its publish in iteration 5, with a
-    small spin limit), the call must (1) leave only valid indices behind, (2) keep the correct prefix,
+    """A cluster FPS needs all members of a cloud resident at once.  When an exchange
+    times out (forced here: P2N_FPS_FAULT makes one member skip its publish in the round that would find sample 6,
+    with a small spin limit), the call must (1) leave only valid indices behind, (2) keep the correct prefix,
     (3) raise FpsExchangeTimeout from fps_check(), and (4) keep its status out of the shared workspace:
     another workspace user in between must not clear it.  Runs in a child process because the tuning
     overrides are read once per process."""
@@ -504,9 +486,10 @@ try:
 except ops.FpsExchangeTimeout:
     print("RAISED")
 assert ops.fps_status("cuda") == 0                    # the check resets the word
-ok = ops.farthest_point_sample(xg[:, :8192].contiguous(), 32, 0)   # single workgroup per cloud: cannot time out
+assert not ops.fps_needs_check(2, 2048)
+ok = ops.farthest_point_sample(xg[:, :2048].contiguous(), 32, 0)   # single workgroup per cloud: cannot time out
 ops.fps_check("cuda")
-assert (ok.cpu().numpy() == oracle.fps(xyz[:, :8192], 32, 0)).all()
+assert (ok.cpu().numpy() == oracle.fps(xyz[:, :2048], 32, 0)).all()
 print("DONE")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, P2N_FPS_FAULT="5", P2N_FPS_SPIN="2000")

@@ -22,13 +22,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                       "prune": os.environ.get("P2N_FPS_PRUNE", "auto"), "ms": round(ms, 4), "us_per_sample": round(1e3 * ms / M, 4),
                       "checksum": chk, "status": ops.fps_status("cuda")}))
 else:
-    shapes = [(1, 40000, 10000, ["auto", 8, 16, 32, 64], "0"), (8, 40000, 2000, ["auto", 8, 16, 32], "0"),
-              (1, 150000, 4000, ["auto", 32, 64], "0"), (1, 1000000, 2000, ["auto"], "0"),
-              (16, 8192, 2048, [1, 4, 8, 16], "1"), (1, 8192, 2048, [1, 8, 16, 32], "1"), (16, 2048, 512, [1, 4, 8, 16], "1")]
+    shapes = [(1, 40000, 10000, ["auto", 16, 32], "0"), (8, 40000, 2000, ["auto", 32], "0"),
+              (1, 150000, 4000, ["auto", 32], "0"),
+              (16, 8192, 2048, ["auto", 1, 16, 32], "1"), (1, 8192, 2048, ["auto", 1, 32], "1"), (16, 2048, 512, ["auto", 1, 16], "1"),
+              (32, 8192, 2048, ["auto"], "1"), (1, 4096, 1024, ["auto", 1], "1")]
     for (B, N, M, gs, noprune) in shapes:
         for g in gs:
-            for rounds in ("on", "-1"):
+            for rounds in ("on", "-1", "2"):
                 if rounds == "-1" and g not in ("auto", 1, 32): continue
+                if rounds == "2" and g == 1: continue
                 env = dict(os.environ)
                 for k in ("P2N_FPS_G", "P2N_FPS_ROUNDS", "P2N_FPS_PRUNE"): env.pop(k, None)
                 if g != "auto": env["P2N_FPS_G"] = str(g)

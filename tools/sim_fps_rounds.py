@@ -38,7 +38,7 @@ def fps_rounds(P, M, start, G, top=1):
         for r, j in enumerate(order):
             d, ni = k1[j]; i = -ni
             if r > 0 and not d > S: break
-            if any(sqd(P[i:i + 1], P[a])[0] < d for a in acc): break
+            if any(sqd(P[i:i + 1], P[a])[0] < d or not np.isfinite(P[a].sum()) for a in acc): break
             acc.append(i)
             if len(out) + len(acc) >= M: break
         for a in acc:
