@@ -127,8 +127,25 @@ def fps_leg(device):
     e1.record()
     torch.cuda.synchronize(device)
     ms8 = e0.elapsed_time(e1)
+    def once(B, N, M, seed, kind="scannet"):
+        pts = torch.from_numpy(np.ascontiguousarray(make_batch(B, N, seed, kind)[:, :, :3])).to(device)
+        ops.farthest_point_sample(pts, M)
+        torch.cuda.synchronize(device)
+        e0.record()
+        ops.farthest_point_sample(pts, M)
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1)
     return {"ms_per_40k_scene": ms, "npoint": npoint, "us_per_sample": 1e3 * ms / npoint,
-            "ms_per_40k_scene_batch_of_8": ms8 / 8, "status": ops.fps_status(device)}
+            "ms_per_40k_scene_batch_of_8": ms8 / 8,
+            "ms_16x8192_to_2048": once(16, 8192, 2048, 11),             # the hierarchical sibling's first level
+            "ms_1m_to_16384": once(1, 1_000_000, 16384, 4, "lidar"),    # BASELINE.json configs[4]
+            "members_per_cloud": {"8192": ops._lib.lib().p2n_fps_workgroups_per_cloud(16, 8192),
+                                  "40000": ops._lib.lib().p2n_fps_workgroups_per_cloud(1, 40000),
+                                  "1000000": ops._lib.lib().p2n_fps_workgroups_per_cloud(1, 1000000)},
+            "note": "cluster kernels accept several samples per exchange round (every published best that provably is the "
+                    "sequential algorithm's next sample); indices bit-identical to the one-at-a-time algorithm",
+            "status": ops.fps_status(device)}
 
 
 def bf16_leg(model, x, lib, steps):

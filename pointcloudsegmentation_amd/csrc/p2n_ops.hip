@@ -438,12 +438,12 @@ __device__ __forceinline__ FrDecision fr_decide(const bool mine, const unsigned 
     return D;
 }
 
-template <int PPT>
-__global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
-    constexpr int T = 256;
+template <int T, int PPT, bool LDSXYZ>
+__global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {
+    constexpr int NWV = T / 64;
     static_assert(PPT % 2 == 0, "points are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) float lxyz[];
-    __shared__ unsigned wv[4][4];                                     // per wave: best distance bits, inverted index, second best
+    __shared__ unsigned wv[NWV][4];                                     // per wave: best distance bits, inverted index, second best
     __shared__ __attribute__((aligned(16))) float wl[2][FR_MAXW][4];  // the samples a round accepted
     __shared__ int nwl[2];
     __shared__ int verdict_s;
@@ -469,7 +469,8 @@ __global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
     u64 *ring = A.slots + (long)cl * (FR_RING + 1) * A.G * FR_SLOT;   // [FR_RING + 1][G][FR_SLOT]; the last row is the XCD census
 
     f32x2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], md[PPT / 2];
-    for (int i = t; i < nloc * 3; i += T) lxyz[i] = P[(long)base * 3 + i];
+    if (LDSXYZ)
+        for (int i = t; i < nloc * 3; i += T) lxyz[i] = P[(long)base * 3 + i];
     if (t < 4) wl[0][0][t] = t < 3 ? P[(long)A.start_idx * 3 + t] : 0.f;
     if (t == 0) nwl[0] = 1;
     __syncthreads();
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
     for (int s = 0; s < PPT; ++s) {
         const int i = t + T * s;
         const bool ok = i < nloc;
-        const float *src = lxyz + i * 3;
+        const float *src = LDSXYZ ? lxyz + i * 3 : P + (long)(base + (ok ? i : 0)) * 3;
         px[s / 2][s & 1] = ok ? src[0] : 0.f;
         py[s / 2][s & 1] = ok ? src[1] : 0.f;
         pz[s / 2][s & 1] = ok ? src[2] : 0.f;
@@ -559,17 +560,17 @@ __global__ __launch_bounds__(256) void p2n_fps_rounds_kernel(FpsArgs A) {
         if (wave == 0) {
             const int nbuf = buf ^ 1;
             // workgroup: the same combination over the four waves
-            const unsigned h4 = lane < 4 ? wv[lane][0] : 0u, l4 = lane < 4 ? wv[lane][1] : 0u, s4 = lane < 4 ? wv[lane][2] : 0u;
+            const unsigned h4 = lane < NWV ? wv[lane][0] : 0u, l4 = lane < NWV ? wv[lane][1] : 0u, s4 = lane < NWV ? wv[lane][2] : 0u;
             const unsigned k1hi = wave_max_u32(h4);
             const unsigned k1lo = wave_max_u32(h4 == k1hi ? l4 : 0u);
-            const unsigned d2 = wave_max_u32((lane < 4 && h4 == k1hi && l4 == k1lo) ? s4 : h4);
+            const unsigned d2 = wave_max_u32((lane < NWV && h4 == k1hi && l4 == k1lo) ? s4 : h4);
             const int li = (int)(0xFFFFFFFFu - k1lo);
             u64 *slot = ring + (long)(round % FR_RING) * A.G * FR_SLOT;
             const unsigned tag = fr_tag(round);
             if (lane < 4 && !(A.fault_it > 0 && it == A.fault_it + 1 && g == A.G - 1)) {
                 const bool real = li >= base && li < base + nloc;   // a workgroup without real points publishes zeros with its losing key
-                const unsigned cxb = real ? __float_as_uint(lxyz[(li - base) * 3 + 0]) : 0u, cyb = real ? __float_as_uint(lxyz[(li - base) * 3 + 1]) : 0u,
-                               czb = real ? __float_as_uint(lxyz[(li - base) * 3 + 2]) : 0u;
+                const float *wsrc = LDSXYZ ? lxyz + (real ? li - base : 0) * 3 : P + (long)(real ? li : 0) * 3;
+                const unsigned cxb = real ? __float_as_uint(wsrc[0]) : 0u, cyb = real ? __float_as_uint(wsrc[1]) : 0u, czb = real ? __float_as_uint(wsrc[2]) : 0u;
                 fr_publish(slot + g * FR_SLOT, lane, tag, k1hi, k1lo, cxb, cyb, czb, d2, fast);
             }
             fr_u32x4 ra = {0, 0, 0, 0}, rc = {0, 0, 0, 0};
@@ -934,17 +935,17 @@ static hipError_t fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int PPT>
+template <int T, int PPT, bool LDSXYZ>
 static hipError_t fps_rounds_launch(const FpsArgs &a, int nb, hipStream_t s) {
-    const size_t lds = (size_t)a.chunk * 12;
+    const size_t lds = LDSXYZ ? (size_t)a.chunk * 12 : 0;
     if (lds > 32 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_fps_rounds_kernel<PPT>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_fps_rounds_kernel<T, PPT, LDSXYZ>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int ps = p2n_prof_begin(P2N_K_FPS, s);
     const unsigned grid = a.xcd_mode ? 8u * a.G * ((nb + 7) / 8) : (unsigned)(nb * a.G);
-    hipLaunchKernelGGL((p2n_fps_rounds_kernel<PPT>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((p2n_fps_rounds_kernel<T, PPT, LDSXYZ>), dim3(grid), dim3(T), lds, s, a);
     p2n_prof_end(ps, s);
     return hipGetLastError();
 }
@@ -1044,21 +1045,26 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         a.xcd_mode = p.G > 1 && p.G * ((nb + 7) / 8) <= ncu / 8 && !p2n_tuning().fps_noxcd;
         a.slots = (u64 *)((char *)workspace + 256);
         a.N = N; a.M = M; a.G = p.G; a.chunk = (N + p.G - 1) / p.G; a.start_idx = start_idx; a.b0 = done;
-        const bool rounds = p.G > 1 && p.T == 256 && p2n_tuning().fps_rounds >= 0;   // P2N_FPS_ROUNDS=-1: one sample per exchange (A/B)
+        const bool rounds = p.G > 1 && p.T != 512 && p2n_tuning().fps_rounds >= 0;   // P2N_FPS_ROUNDS=-1: one sample per exchange (A/B)
         if (p.G > 1)   // launches run in stream order, so they can share the slot region
             P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 256, 0, rounds ? sizeof(u64) * FR_SLOT * (size_t)nb * (FR_RING + 1) * p.G
                                                                             : sizeof(u64) * 4 * (size_t)nb * (M + 1) * p.G, stream));
         hipError_t e = hipErrorInvalidValue;
-        if (rounds) {
+        if (rounds && p.T == 256) {
             switch (p.ppt) {
-                case 2: e = fps_rounds_launch<2>(a, nb, stream); break;
-                case 4: e = fps_rounds_launch<4>(a, nb, stream); break;
-                case 8: e = fps_rounds_launch<8>(a, nb, stream); break;
-                case 16: e = fps_rounds_launch<16>(a, nb, stream); break;
-                case 24: e = fps_rounds_launch<24>(a, nb, stream); break;
-                case 32: e = fps_rounds_launch<32>(a, nb, stream); break;
-                case 40: e = fps_rounds_launch<40>(a, nb, stream); break;
-                case 48: e = fps_rounds_launch<48>(a, nb, stream); break;
+                case 2: e = fps_rounds_launch<256, 2, true>(a, nb, stream); break;
+                case 4: e = fps_rounds_launch<256, 4, true>(a, nb, stream); break;
+                case 8: e = fps_rounds_launch<256, 8, true>(a, nb, stream); break;
+                case 16: e = fps_rounds_launch<256, 16, true>(a, nb, stream); break;
+                case 24: e = fps_rounds_launch<256, 24, true>(a, nb, stream); break;
+                case 32: e = fps_rounds_launch<256, 32, true>(a, nb, stream); break;
+                case 40: e = fps_rounds_launch<256, 40, true>(a, nb, stream); break;
+                case 48: e = fps_rounds_launch<256, 48, true>(a, nb, stream); break;
+            }
+        } else if (rounds) {
+            switch (p.ppt) {
+                case 16: e = fps_rounds_launch<1024, 16, false>(a, nb, stream); break;
+                case 20: e = fps_rounds_launch<1024, 20, false>(a, nb, stream); break;
             }
         } else if (p.T == 256) {
             switch (p.ppt) {
