@@ -358,88 +358,110 @@ __device__ __forceinline__ bool fr_poll(const u64 *rec, unsigned tag, fr_u32x4 &
 // 16 of them -- the usual case -- they are compacted into LDS and all candidate pairs are evaluated at once (lane =
 // (candidate i = lane & 15, other candidate j = lane >> 4 + 4 * pass): is j earlier in key order, and would accepting j
 // lower i's running minimum?); ballots turn the pair results into every candidate's rank and "blocked" flag.  The result
-// lives in candidate space (lane p < n holds candidate p's record).  More than 16 candidates take the serial walk over
-// the candidate mask in member space.  Either way: acc lanes hold an accepted sample's coordinates, rank and index.
+// lives in candidate space (lane p < n holds candidate p's record).  More than 16 candidates are first cut to the 16 largest
+// distances (a serial count over the candidate mask; rare).  acc lanes hold an accepted sample's coordinates, rank and index.
 struct FrDecision { bool acc; unsigned rank; unsigned klo; float x, y, z; };
-__device__ __forceinline__ FrDecision fr_decide(const bool mine, const unsigned khi, const unsigned klo, const float x, const float y,
-                                                const float z, const unsigned d2v, const int room, float4 *rec, u64 *reck,
-                                                const int lane) {
+// R records per lane (record lane + 64 r): clusters of up to 64 R members.
+template <int R>
+__device__ __forceinline__ FrDecision fr_decide(const bool (&mine)[R], const unsigned (&khi)[R], const unsigned (&klo)[R], const float (&x)[R],
+                                                const float (&y)[R], const float (&z)[R], const unsigned (&d2v)[R], const int room, float4 *rec,
+                                                u64 *reck, const int lane) {
     FrDecision D;
-    const unsigned S = wave_max_u32(mine ? d2v : 0u);
-    bool cand = mine && khi > S;
-    u64 cmask = __ballot(cand);
-    if (cmask == 0ull) {   // the largest distance ties somebody's second best: only the overall best is provably next
-        const unsigned ahi = wave_max_u32(mine ? khi : 0u);
-        const unsigned alo = wave_max_u32(mine && khi == ahi ? klo : 0u);
-        cand = mine && khi == ahi && klo == alo;
-        cmask = __ballot(cand);
-    }
-    const int n = (int)__builtin_popcountll(cmask);
-    unsigned rank = 0u;
-    bool blocked = false, candp;
-    if (n <= 16) {
-        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cmask, 0u));
-        if (cand) { rec[pos] = make_float4(x, y, z, __uint_as_float(khi)); reck[pos] = ((u64)khi << 32) | klo; }
-        // one wave writes and reads: LDS serves a wave's instructions in order, so only the compiler has to be told
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int i = lane & 15, jb = lane >> 4;
-        // all reads first (entries past n are stale and masked below), so that their latencies overlap
-        const float4 Ri = rec[i];
-        const u64 ki = reck[i];
-        float4 Rj[4];
-        u64 kj[4];
+    unsigned dmax = 0u;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) { Rj[pass] = rec[jb + 4 * pass]; kj[pass] = reck[jb + 4 * pass]; }
-        const u64 col = 0x0001000100010001ull << i;
-        const unsigned colo = (unsigned)col, cohi = (unsigned)(col >> 32);
-        const bool iv = i < n;
-        u64 many = 0ull;
+    for (int r = 0; r < R; ++r) dmax = (mine[r] && d2v[r] > dmax) ? d2v[r] : dmax;
+    const unsigned S = wave_max_u32(dmax);
+    bool cand[R];
+    u64 cmask[R];
+    int n = 0;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            if (4 * pass < n) {   // uniform
-                const bool bigger = iv && jb + 4 * pass < n && kj[pass] > ki;
-                const float dd = sqdist3(Ri.x, Ri.y, Ri.z, Rj[pass].x, Rj[pass].y, Rj[pass].z);   // the update's own expression
-                // a sample with a non-finite coordinate never clears its own running minimum (p - p is NaN): the
-                // sequential algorithm picks it again at once, so nothing may follow it within a round
-                const bool sticky = !__builtin_isfinite((Rj[pass].x + Rj[pass].y) + Rj[pass].z);
-                const u64 mb = __ballot(bigger);
-                many |= __ballot(bigger && (dd < Ri.w || sticky));
-                rank += (unsigned)__builtin_popcount((unsigned)mb & colo) + (unsigned)__builtin_popcount((unsigned)(mb >> 32) & cohi);
+    for (int r = 0; r < R; ++r) { cand[r] = mine[r] && khi[r] > S; cmask[r] = __ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
+    if (n > 16) {
+        // keep the candidates with the 16 largest distances (a set closed from the top, ties kept or dropped together:
+        // the accepted samples are a prefix of the key order anyway)
+        unsigned ge[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) ge[r] = 0u;
+#pragma unroll
+        for (int r2 = 0; r2 < R; ++r2) {
+            u64 cm = cmask[r2];
+            while (cm) {
+                const int i = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)khi[r2], i);
+#pragma unroll
+                for (int r = 0; r < R; ++r) ge[r] += v >= khi[r] ? 1u : 0u;
             }
         }
-        blocked = (many & col) != 0ull;
-        candp = lane < n;
-        D.x = Ri.x; D.y = Ri.y; D.z = Ri.z; D.klo = (unsigned)ki;
-    } else {
-        u64 cm = cmask;
-        const float mydist = __uint_as_float(khi);
-        while (cm) {
-            const int i = __builtin_ctzll(cm);
-            cm &= cm - 1;
-            const unsigned ohi = (unsigned)__builtin_amdgcn_readlane((int)khi, i), olo = (unsigned)__builtin_amdgcn_readlane((int)klo, i);
-            const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
-            const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), i));
-            const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), i));
-            const bool bigger = ohi > khi || (ohi == khi && olo > klo);
-            rank += bigger ? 1u : 0u;
-            const float dd = sqdist3(x, y, z, ox, oy, oz);
-            blocked = blocked || (bigger && (dd < mydist || !__builtin_isfinite((ox + oy) + oz)));
-        }
-        candp = cand;
-        D.x = x; D.y = y; D.z = z; D.klo = klo;
+        n = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { cand[r] = cand[r] && ge[r] <= 16u; cmask[r] = __ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
     }
-    const unsigned rblk = (candp && blocked) ? rank : 64u;
-    const int rstar = 64 - (int)wave_max_u32(64u - rblk);   // rank of the first candidate an earlier one would change
+    if (n == 0) {   // the largest distance ties somebody's second best (or 17 bests tie): only the overall best is provably next
+        unsigned hm = 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) hm = (mine[r] && khi[r] > hm) ? khi[r] : hm;
+        const unsigned ahi = wave_max_u32(hm);
+        unsigned lm = 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) lm = (mine[r] && khi[r] == ahi && klo[r] > lm) ? klo[r] : lm;
+        const unsigned alo = wave_max_u32(lm);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { cand[r] = mine[r] && khi[r] == ahi && klo[r] == alo; cmask[r] = __ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
+    }
+    // candidates compacted into LDS in (r, lane) order
+    int off = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cmask[r] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cmask[r], 0u));
+        if (cand[r]) { rec[pos] = make_float4(x[r], y[r], z[r], __uint_as_float(khi[r])); reck[pos] = ((u64)khi[r] << 32) | klo[r]; }
+        off += (int)__builtin_popcountll(cmask[r]);
+    }
+    // one wave writes and reads: LDS serves a wave's instructions in order, so only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int i = lane & 15, jb = lane >> 4;
+    // all reads first (entries past n are stale and masked below), so that their latencies overlap
+    const float4 Ri = rec[i];
+    const u64 ki = reck[i];
+    float4 Rj[4];
+    u64 kj[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) { Rj[pass] = rec[jb + 4 * pass]; kj[pass] = reck[jb + 4 * pass]; }
+    const u64 col = 0x0001000100010001ull << i;
+    const unsigned colo = (unsigned)col, cohi = (unsigned)(col >> 32);
+    const bool iv = i < n;
+    u64 many = 0ull;
+    unsigned rank = 0u;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        if (4 * pass < n) {   // uniform
+            const bool bigger = iv && jb + 4 * pass < n && kj[pass] > ki;
+            const float dd = sqdist3(Ri.x, Ri.y, Ri.z, Rj[pass].x, Rj[pass].y, Rj[pass].z);   // the update's own expression
+            // a sample with a non-finite coordinate never clears its own running minimum (p - p is NaN): the
+            // sequential algorithm picks it again at once, so nothing may follow it within a round
+            const bool sticky = !__builtin_isfinite((Rj[pass].x + Rj[pass].y) + Rj[pass].z);
+            const u64 mb = __ballot(bigger);
+            many |= __ballot(bigger && (dd < Ri.w || sticky));
+            rank += (unsigned)__builtin_popcount((unsigned)mb & colo) + (unsigned)__builtin_popcount((unsigned)(mb >> 32) & cohi);
+        }
+    }
+    const bool candp = lane < n;
+    int rstar = 64;   // rank of the first candidate an earlier one would change
+    if (many != 0ull) {
+        const unsigned rblk = (candp && (many & col) != 0ull) ? rank : 64u;
+        rstar = 64 - (int)wave_max_u32(64u - rblk);
+    }
     const int limit = rstar < room ? rstar : room;
     D.acc = candp && (int)rank < limit;
     D.rank = rank;
+    D.x = Ri.x; D.y = Ri.y; D.z = Ri.z; D.klo = (unsigned)ki;
     return D;
 }
 
-template <int T, int PPT, bool LDSXYZ>
-__global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {
+template <int T, int PPT, bool LDSXYZ, int R>
+__global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {   // R: records per decision lane (members <= 64 R)
     constexpr int NWV = T / 64;
     static_assert(PPT % 2 == 0, "points are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) float lxyz[];
@@ -485,7 +507,7 @@ __global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {
         md[s / 2][s & 1] = ok ? __int_as_float(0x7f800000) : 0.f;
     }
     bool dead = false, census_dead = false, fast = false;
-    if (A.xcd_mode) {   // XCD census, as in the kernel above
+    if (A.xcd_mode && A.G <= 64) {   // XCD census, as in the kernel above
         if (wave == 0) {
             u64 *cs = ring + (long)FR_RING * A.G * FR_SLOT;
             const unsigned myx = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 0xF;
@@ -573,22 +595,36 @@ __global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {
                 const unsigned cxb = real ? __float_as_uint(wsrc[0]) : 0u, cyb = real ? __float_as_uint(wsrc[1]) : 0u, czb = real ? __float_as_uint(wsrc[2]) : 0u;
                 fr_publish(slot + g * FR_SLOT, lane, tag, k1hi, k1lo, cxb, cyb, czb, d2, fast);
             }
-            fr_u32x4 ra = {0, 0, 0, 0}, rc = {0, 0, 0, 0};
-            const bool mine = lane < A.G;
+            fr_u32x4 ra[R], rc[R];
+            bool mine[R], ready[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { ra[r] = fr_u32x4{0, 0, 0, 0}; rc[r] = fr_u32x4{0, 0, 0, 0}; mine[r] = lane + 64 * r < A.G; ready[r] = !mine[r]; }
             int spins = 0;
-            bool ok, ready = !mine;
+            bool ok;
             for (int d = 0; d < A.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             for (;;) {
-                if (!ready) ready = fr_poll(slot + lane * FR_SLOT, tag, ra, rc);
-                ok = __all(ready);
+                bool all = true;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!ready[r]) ready[r] = fr_poll(slot + (lane + 64 * r) * FR_SLOT, tag, ra[r], rc[r]);
+                    all = all && ready[r];
+                }
+                ok = __all(all);
                 if (ok || ++spins > A.spin_limit) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            const unsigned khi = mine ? ra[0] : 0u, klo = mine ? ((ra[1] & 0xFFFFu) | (ra[3] << 16)) : 0u;
+            unsigned khi[R], klo[R], d2v[R];
+            float cx_[R], cy_[R], cz_[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                khi[r] = mine[r] ? ra[r][0] : 0u;
+                klo[r] = mine[r] ? ((ra[r][1] & 0xFFFFu) | (ra[r][3] << 16)) : 0u;
+                d2v[r] = (rc[r][1] & 0xFFFFu) | (rc[r][3] << 16);
+                cx_[r] = __uint_as_float(ra[r][2]); cy_[r] = __uint_as_float(rc[r][0]); cz_[r] = __uint_as_float(rc[r][2]);
+            }
             int room = A.M - it;
             if (A.fault_it > 0 && it <= A.fault_it && room > A.fault_it + 1 - it) room = A.fault_it + 1 - it;   // test hook: a round boundary at the faulted sample
-            const FrDecision D = fr_decide(mine, khi, klo, __uint_as_float(ra[2]), __uint_as_float(rc[0]), __uint_as_float(rc[2]),
-                                           (rc[1] & 0xFFFFu) | (rc[3] << 16), room, rec, reck, lane);
+            const FrDecision D = fr_decide<R>(mine, khi, klo, cx_, cy_, cz_, d2v, room, rec, reck, lane);
             const int widx = (int)(0xFFFFFFFFu - D.klo);
             int m = (int)__builtin_popcountll(__ballot(D.acc));
             if (!ok || m < 1 || __any(D.acc && (widx < 0 || widx >= A.N))) m = -1;
@@ -761,11 +797,12 @@ __global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {
             __builtin_amdgcn_s_sleep(1);
         }
         FR_T(4);
-        const unsigned khi = mine ? ra[0] : 0u, klo = mine ? ((ra[1] & 0xFFFFu) | (ra[3] << 16)) : 0u;
+        const bool mine1[1] = {mine};
+        const unsigned khi1[1] = {mine ? ra[0] : 0u}, klo1[1] = {mine ? ((ra[1] & 0xFFFFu) | (ra[3] << 16)) : 0u}, d2v1[1] = {(rc[1] & 0xFFFFu) | (rc[3] << 16)};
+        const float x1[1] = {__uint_as_float(ra[2])}, y1[1] = {__uint_as_float(rc[0])}, z1[1] = {__uint_as_float(rc[2])};
         int room = A.M - it;
         if (A.fault_it > 0 && it <= A.fault_it && room > A.fault_it + 1 - it) room = A.fault_it + 1 - it;
-        const FrDecision D = fr_decide(mine, khi, klo, __uint_as_float(ra[2]), __uint_as_float(rc[0]), __uint_as_float(rc[2]),
-                                       (rc[1] & 0xFFFFu) | (rc[3] << 16), room, rec, reck, lane);
+        const FrDecision D = fr_decide<1>(mine1, khi1, klo1, x1, y1, z1, d2v1, room, rec, reck, lane);
         x = D.x; y = D.y; z = D.z;
         const int widx = (int)(0xFFFFFFFFu - D.klo);
         am = __ballot(D.acc);
@@ -853,7 +890,8 @@ static FpsPlan fps_plan(int B, int N) {
     const int ncu = fps_cus();
     int gmax = ncu / (B < ncu ? B : ncu);   // all B*G workgroups must be co-resident
     if (gmax < 1) gmax = 1;
-    if (gmax > 64) gmax = 64;
+    const int gcap = p2n_tuning().fps_rounds >= 0 ? 256 : 64;   // members one decision wave can serve: 4 records per lane in the round kernels, 1 in the one-sample kernel
+    if (gmax > gcap) gmax = gcap;
     int G;
     const int gmin256 = (N + FPS_LDS_POINTS - 1) / FPS_LDS_POINTS;
     if (gmin256 <= gmax) {
@@ -870,7 +908,10 @@ static FpsPlan fps_plan(int B, int N) {
             const int per_xcd = ncu / 8;
             const int share = per_xcd / ((B + 7) / 8);          // CUs of an XCD per cloud when the launch's clouds are dealt over the 8 XCDs
             G = (N + 1023) / 1024;
-            if (share >= gmin256) { if (G > share) G = share; }   // the cluster stays inside one XCD (plain-store exchange through its L2)
+            // the one-sample kernel stays inside one XCD (plain-store exchange through its L2) whenever the cloud fits it; the
+            // round kernels only see clouds beyond 100,000 points by default, where ~1,000 points per member across XCDs
+            // measured faster than 32 fat members in one (profiles/r03_i_fps_large.txt: 150k 2.96 -> 2.53 ms, 300k 6.76 -> 5.20)
+            if (share >= gmin256 && (p2n_tuning().fps_rounds < 0 || N <= 100000)) { if (G > share) G = share; }
             if (G > gmax) G = gmax;
             if (G < gmin256) G = gmin256;
         }
@@ -878,11 +919,13 @@ static FpsPlan fps_plan(int B, int N) {
     } else {
         const int cap = 1024 * 20;
         G = (N + cap - 1) / cap;
-        if (G <= gmax) {   // spare CUs: ~8 points per thread
+        const int g1024 = gmax < 64 ? gmax : 64;   // the 1024-thread kernels read one record per decision lane
+        if (G <= g1024) {   // spare CUs: ~8 points per thread
             int gw = (N + 8191) / 8192;
-            if (gw > gmax) gw = gmax;
+            if (gw > g1024) gw = g1024;
             if (gw > G) G = gw;
         }
+        if (G > g1024) return p;
         p.T = 1024;
     }
     if (const int g = p2n_tuning().fps_g) {   // tuning override (tools/fps_sweep.py)
@@ -908,7 +951,7 @@ static FpsPlan fps_plan(int B, int N) {
 // exchange slots of B clouds at the largest cluster (64 workgroups): per-iteration slots of the one-sample kernel or
 // the record ring of the rounds kernel, whichever is larger
 static size_t fps_slot_bytes(int B, int M, bool one_sample_kernel) {
-    const size_t a = one_sample_kernel ? sizeof(u64) * 4 * (size_t)(M + 1) * 64 : 0, r = sizeof(u64) * FR_SLOT * (size_t)(FR_RING + 1) * 64;
+    const size_t a = one_sample_kernel ? sizeof(u64) * 4 * (size_t)(M + 1) * 64 : 0, r = sizeof(u64) * FR_SLOT * (size_t)(FR_RING + 1) * 256;
     return (size_t)B * (a > r ? a : r);
 }
 
@@ -935,17 +978,17 @@ static hipError_t fps_launch(const FpsArgs &a, int nb, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int T, int PPT, bool LDSXYZ>
+template <int T, int PPT, bool LDSXYZ, int R>
 static hipError_t fps_rounds_launch(const FpsArgs &a, int nb, hipStream_t s) {
     const size_t lds = LDSXYZ ? (size_t)a.chunk * 12 : 0;
     if (lds > 32 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_fps_rounds_kernel<T, PPT, LDSXYZ>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p2n_fps_rounds_kernel<T, PPT, LDSXYZ, R>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int ps = p2n_prof_begin(P2N_K_FPS, s);
     const unsigned grid = a.xcd_mode ? 8u * a.G * ((nb + 7) / 8) : (unsigned)(nb * a.G);
-    hipLaunchKernelGGL((p2n_fps_rounds_kernel<T, PPT, LDSXYZ>), dim3(grid), dim3(T), lds, s, a);
+    hipLaunchKernelGGL((p2n_fps_rounds_kernel<T, PPT, LDSXYZ, R>), dim3(grid), dim3(T), lds, s, a);
     p2n_prof_end(ps, s);
     return hipGetLastError();
 }
@@ -1037,7 +1080,7 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
             nb = nb / 2;
             p = fps_plan(nb, N);
         }
-        P2N_REQUIRE(p.G >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 64 * 1024 * 20);
+        P2N_REQUIRE(p.G >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 256 * FPS_LDS_POINTS);
         FpsArgs a;
         a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault; a.poll_delay = p2n_tuning().fps_pd;
         a.nb = nb;
@@ -1050,21 +1093,32 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
             P2N_CHECK_HIP(hipMemsetAsync((char *)workspace + 256, 0, rounds ? sizeof(u64) * FR_SLOT * (size_t)nb * (FR_RING + 1) * p.G
                                                                             : sizeof(u64) * 4 * (size_t)nb * (M + 1) * p.G, stream));
         hipError_t e = hipErrorInvalidValue;
-        if (rounds && p.T == 256) {
+        if (rounds && p.T == 256 && p.G <= 64) {
             switch (p.ppt) {
-                case 2: e = fps_rounds_launch<256, 2, true>(a, nb, stream); break;
-                case 4: e = fps_rounds_launch<256, 4, true>(a, nb, stream); break;
-                case 8: e = fps_rounds_launch<256, 8, true>(a, nb, stream); break;
-                case 16: e = fps_rounds_launch<256, 16, true>(a, nb, stream); break;
-                case 24: e = fps_rounds_launch<256, 24, true>(a, nb, stream); break;
-                case 32: e = fps_rounds_launch<256, 32, true>(a, nb, stream); break;
-                case 40: e = fps_rounds_launch<256, 40, true>(a, nb, stream); break;
-                case 48: e = fps_rounds_launch<256, 48, true>(a, nb, stream); break;
+                case 2: e = fps_rounds_launch<256, 2, true, 1>(a, nb, stream); break;
+                case 4: e = fps_rounds_launch<256, 4, true, 1>(a, nb, stream); break;
+                case 8: e = fps_rounds_launch<256, 8, true, 1>(a, nb, stream); break;
+                case 16: e = fps_rounds_launch<256, 16, true, 1>(a, nb, stream); break;
+                case 24: e = fps_rounds_launch<256, 24, true, 1>(a, nb, stream); break;
+                case 32: e = fps_rounds_launch<256, 32, true, 1>(a, nb, stream); break;
+                case 40: e = fps_rounds_launch<256, 40, true, 1>(a, nb, stream); break;
+                case 48: e = fps_rounds_launch<256, 48, true, 1>(a, nb, stream); break;
+            }
+        } else if (rounds && p.T == 256) {   // more than 64 members: four records per decision lane
+            switch (p.ppt) {
+                case 2: e = fps_rounds_launch<256, 2, true, 4>(a, nb, stream); break;
+                case 4: e = fps_rounds_launch<256, 4, true, 4>(a, nb, stream); break;
+                case 8: e = fps_rounds_launch<256, 8, true, 4>(a, nb, stream); break;
+                case 16: e = fps_rounds_launch<256, 16, true, 4>(a, nb, stream); break;
+                case 24: e = fps_rounds_launch<256, 24, true, 4>(a, nb, stream); break;
+                case 32: e = fps_rounds_launch<256, 32, true, 4>(a, nb, stream); break;
+                case 40: e = fps_rounds_launch<256, 40, true, 4>(a, nb, stream); break;
+                case 48: e = fps_rounds_launch<256, 48, true, 4>(a, nb, stream); break;
             }
         } else if (rounds) {
             switch (p.ppt) {
-                case 16: e = fps_rounds_launch<1024, 16, false>(a, nb, stream); break;
-                case 20: e = fps_rounds_launch<1024, 20, false>(a, nb, stream); break;
+                case 16: e = fps_rounds_launch<1024, 16, false, 1>(a, nb, stream); break;
+                case 20: e = fps_rounds_launch<1024, 20, false, 1>(a, nb, stream); break;
             }
         } else if (p.T == 256) {
             switch (p.ppt) {

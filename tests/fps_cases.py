@@ -47,6 +47,7 @@ def cases(small: bool):
     out.append(("30k_x40", _cloud(40, 30000, seed=17), 40, 0))               # members per cloud capped by the other clouds
     out.append(("4096_x70", _cloud(70, 4096, seed=18), 64, 1))               # more clouds than one launch takes
     out.append(("150k", _cloud(1, 150000, seed=19), 200, 0))
+    out.append(("300k", _cloud(1, 300000, seed=24), 300, 7))                 # more than 64 members: several records per decision lane
     out.append(("odd_split", _cloud(1, 4099, seed=20), 4099, 4098))          # ragged last member, all points sampled
     if small:
         out.append(("n5", _cloud(2, 5, seed=21), 5, 3))
