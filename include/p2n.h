@@ -295,6 +295,13 @@ int p2n_pointwise_layer(const float *in, int B, int Cin, long L, const float *W,
                         const float *shift, int relu, int Cout, float *out,
                         void *workspace, size_t workspace_bytes, void *stream);
 int p2n_group_max(const float *in, int B, int C, int M, int ns, float *out, void *stream);
+/* The same maximum on the CHANNEL-MAJOR output of p2n_mlp_train_forward, for set-abstraction levels in training (no
+ * counterpart in the reference: it has no hierarchical levels; replaces y.view(B,C,M,ns).max(dim=3) and its autograd
+ * around the train-mode shared MLP): in (C, ld), group g = columns g*ns .. g*ns+ns-1 (g < G, G*ns <= ld, ld % 4 == 0)
+ * -> out (C, G) and arg (C, G) = first position of the maximum; the backward writes din (C, ld) = gout at the recorded
+ * position, zero elsewhere (pad columns included), i.e. exactly the d out of p2n_mlp_train_backward. */
+int p2n_group_max_cm(const float *in, int C, long ld, long G, int ns, float *out, unsigned char *arg, void *stream);
+int p2n_group_max_cm_bwd(const float *gout, const unsigned char *arg, int C, long G, int ns, long ld, float *din, void *stream);
 
 /* ---- fused hierarchical levels (no reference counterpart: the north star names set-abstraction and
  * feature-propagation levels, the reference has none; parity unpinned).  One kernel per level: the grouped

@@ -25,6 +25,7 @@ c_i = ctypes.c_void_p      # device int32*
 c_vp = ctypes.c_void_p
 c_int = ctypes.c_int
 c_sz = ctypes.c_size_t
+c_long = ctypes.c_long
 c_float = ctypes.c_float
 
 # name -> (restype, argtypes); mirrors include/p2n.h one to one
@@ -79,6 +80,8 @@ SIGNATURES = {
     "p2n_pointwise_layer_workspace_bytes": (c_sz, [c_int, c_int]),
     "p2n_pointwise_layer": (c_int, [c_f, c_int, c_int, ctypes.c_long, c_f, c_f, c_f, c_int, c_int, c_f, c_vp, c_sz, c_vp]),
     "p2n_group_max": (c_int, [c_f, c_int, c_int, c_int, c_int, c_f, c_vp]),
+    "p2n_group_max_cm": (c_int, [c_f, c_int, c_long, c_long, c_int, c_f, c_vp, c_vp]),
+    "p2n_group_max_cm_bwd": (c_int, [c_f, c_vp, c_int, c_long, c_int, c_long, c_f, c_vp]),
     "p2n_level_packed_floats": (ctypes.c_long, [c_int, c_int, c_vp, c_int]),
     "p2n_level_pack": (c_int, [c_int, c_int, c_vp, c_vp, c_int, ctypes.c_double, c_f, c_vp]),
     "p2n_sa_level": (c_int, [c_f, c_int, c_f, c_f, c_int, c_i, c_int, c_int, c_int, c_int, c_int, c_vp, c_f, c_f, c_vp]),

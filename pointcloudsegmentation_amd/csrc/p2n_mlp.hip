@@ -137,6 +137,112 @@ extern "C" int p2n_pointwise_layer(const float *in, int B, int Cin, long L, cons
     return P2N_OK;
 }
 
+// ---- group maximum on the channel-major output of a train-mode shared MLP (set-abstraction levels in training) ------
+// in (C, ld): columns g*ns .. g*ns+ns-1 of a row are group g (g < G).  out (C, G) = the group's maximum, arg (C, G) =
+// the first position that attains it (what the backward routes the gradient to).  ns in {8, 16, 32, 64}: ns/4 lanes
+// read one group as consecutive 16-byte pieces (a wave reads 1 KiB contiguous per step) and reduce by xor-shuffles;
+// other ns: one thread per group.  Keys order as (value, lower position first); a NaN with its sign bit clear is the
+// largest value, as in torch.max.
+__device__ __forceinline__ unsigned p2n_ordered_bits(float v) {
+    unsigned b = __float_as_uint(v);
+    b = b == 0x80000000u ? 0u : b;                    // -0 == +0: the first of them is the first maximum
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void p2n_group_max_cm_kernel(const float *__restrict__ in, long ld, long G, float *__restrict__ out,
+                                                               unsigned char *__restrict__ arg) {
+    constexpr int LPG = NS / 4;                       // lanes per group
+    const int c = blockIdx.y;
+    const long piece = (long)blockIdx.x * 256 + threadIdx.x;      // 16-byte piece of the row
+    const long g = piece / LPG;
+    const int sub = (int)(piece % LPG);
+    const bool ok = g < G;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *reinterpret_cast<const float4 *>(in + (long)c * ld + piece * 4);
+    unsigned long long k = 0ull;
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long kj = ((unsigned long long)p2n_ordered_bits(e[j]) << 32) | (unsigned)(255 - (sub * 4 + j));
+        k = kj > k ? kj : k;
+    }
+#pragma unroll
+    for (int m = 1; m < LPG; m <<= 1) {
+        const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(k >> 32), m) << 32) | (unsigned)__shfl_xor((int)k, m);
+        k = o > k ? o : k;
+    }
+    if (ok && sub == 0) {
+        const unsigned ob = (unsigned)(k >> 32);
+        out[(long)c * G + g] = __uint_as_float(ob ^ ((ob >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        arg[(long)c * G + g] = (unsigned char)(255 - (unsigned)(k & 0xFFu));
+    }
+}
+
+__global__ __launch_bounds__(256) void p2n_group_max_cm_any_kernel(const float *__restrict__ in, long ld, long G, int ns,
+                                                                   float *__restrict__ out, unsigned char *__restrict__ arg) {
+    const int c = blockIdx.y;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const float *q = in + (long)c * ld + g * ns;
+    unsigned best = p2n_ordered_bits(q[0]);
+    int pos = 0;
+    for (int s = 1; s < ns; ++s) {
+        const unsigned b = p2n_ordered_bits(q[s]);
+        if (b > best) { best = b; pos = s; }
+    }
+    out[(long)c * G + g] = q[pos];   // (-0 where the group's first maximum is -0; the cooperative kernels return +0: equal)
+    arg[(long)c * G + g] = (unsigned char)pos;
+}
+
+// backward: din (C, ld) = gout[c][g] at column g*ns + arg[c][g], zero elsewhere (pad columns G*ns .. ld-1 included)
+__global__ __launch_bounds__(256) void p2n_group_max_cm_bwd_kernel(const float *__restrict__ gout, const unsigned char *__restrict__ arg,
+                                                                   long G, int ns, long ld, float *__restrict__ din) {
+    const int c = blockIdx.y;
+    const long col = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (col >= ld) return;
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long cj = col + j, g = cj / ns;
+        e[j] = (g < G && (int)(cj - g * ns) == (int)arg[(long)c * G + g]) ? gout[(long)c * G + g] : 0.f;
+    }
+    *reinterpret_cast<float4 *>(din + (long)c * ld + col) = make_float4(e[0], e[1], e[2], e[3]);
+}
+
+extern "C" int p2n_group_max_cm(const float *in, int C, long ld, long G, int ns, float *out, unsigned char *arg, void *stream_) {
+    P2N_REQUIRE(C >= 0 && G >= 0 && ns >= 1 && ns <= 255 && ld >= G * ns && ld % 4 == 0, "p2n_group_max_cm: bad shape C=%d ld=%ld G=%ld ns=%d", C, ld, G, ns);
+    if (C == 0 || G == 0) return P2N_OK;
+    P2N_REQUIRE(in && out && arg, "p2n_group_max_cm: null pointer");
+    P2N_REQUIRE(C <= 65535, "p2n_group_max_cm: more than 65,535 channels");
+    hipStream_t s = (hipStream_t)stream_;
+    const int ps = p2n_prof_begin(P2N_K_GROUP_MAX, s);
+    const unsigned gx = (unsigned)((G * (ns / 4) + 255) / 256);
+    switch (ns) {
+        case 8: hipLaunchKernelGGL(p2n_group_max_cm_kernel<8>, dim3(gx, C), dim3(256), 0, s, in, ld, G, out, arg); break;
+        case 16: hipLaunchKernelGGL(p2n_group_max_cm_kernel<16>, dim3(gx, C), dim3(256), 0, s, in, ld, G, out, arg); break;
+        case 32: hipLaunchKernelGGL(p2n_group_max_cm_kernel<32>, dim3(gx, C), dim3(256), 0, s, in, ld, G, out, arg); break;
+        case 64: hipLaunchKernelGGL(p2n_group_max_cm_kernel<64>, dim3(gx, C), dim3(256), 0, s, in, ld, G, out, arg); break;
+        default: hipLaunchKernelGGL(p2n_group_max_cm_any_kernel, dim3((unsigned)((G + 255) / 256), C), dim3(256), 0, s, in, ld, G, ns, out, arg);
+    }
+    p2n_prof_end(ps, s);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
+extern "C" int p2n_group_max_cm_bwd(const float *gout, const unsigned char *arg, int C, long G, int ns, long ld, float *din, void *stream_) {
+    P2N_REQUIRE(C >= 0 && G >= 0 && ns >= 1 && ns <= 255 && ld >= G * ns && ld % 4 == 0, "p2n_group_max_cm_bwd: bad shape C=%d ld=%ld G=%ld ns=%d", C, ld, G, ns);
+    if (C == 0 || ld == 0) return P2N_OK;
+    P2N_REQUIRE(gout && arg && din, "p2n_group_max_cm_bwd: null pointer");
+    P2N_REQUIRE(C <= 65535, "p2n_group_max_cm_bwd: more than 65,535 channels");
+    hipStream_t s = (hipStream_t)stream_;
+    const int ps = p2n_prof_begin(P2N_K_GROUP_MAX, s);
+    hipLaunchKernelGGL(p2n_group_max_cm_bwd_kernel, dim3((unsigned)((ld / 4 + 255) / 256), C), dim3(256), 0, s, gout, arg, G, ns, ld, din);
+    p2n_prof_end(ps, s);
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
 extern "C" int p2n_group_max(const float *in, int B, int C, int M, int ns, float *out, void *stream) {
     P2N_REQUIRE(B >= 0 && C >= 0 && M >= 0 && ns >= 1, "p2n_group_max: bad shape");
     const long rows = (long)B * C * M;

@@ -173,7 +173,7 @@ class _SharedMLPTrainFn(torch.autograd.Function):
     BatchNorm with the running buffers updated in place, as nn.BatchNorm1d in train() mode)."""
 
     @staticmethod
-    def forward(ctx, x, dims, last_plain, momentum, buffers, *params):
+    def forward(ctx, x, dims, last_plain, momentum, buffers, group, *params):
         L_ = _lib.lib()
         x = _rt.require_cuda_f32(x, "x")
         B, C, L = x.shape
@@ -207,9 +207,22 @@ class _SharedMLPTrainFn(torch.autograd.Function):
             _lib.check(L_.p2n_mlp_train_forward(x_cm.data_ptr(), P, nl, arr, int(last_plain), ptrs, float(momentum),
                                                 out_cm.data_ptr(), ws.data_ptr(), ws.numel(), _rt.stream_handle(dev)),
                        "p2n_mlp_train_forward")
-        ctx.save_for_backward(x_cm, ws, *params)
-        ctx.meta = (dims, bool(last_plain), B, L, P, Ppad, table)
+        ctx.meta = (dims, bool(last_plain), B, L, P, Ppad, table, group)
         ctx.done = False
+        if group:
+            # maximum over groups of `group` consecutive columns (a set-abstraction level's neighbours) taken on the
+            # channel-major output: the (B,C,M,ns) tensor, torch.max and its scatter backward never exist
+            if L % group:
+                raise ValueError(f"columns per cloud ({L}) are not a multiple of the group size ({group})")
+            G = P // group
+            mx = torch.empty((dims[-1], G), dtype=torch.float32, device=dev)
+            arg = torch.empty((dims[-1], G), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L_.p2n_group_max_cm(out_cm.data_ptr(), dims[-1], Ppad, G, group, mx.data_ptr(), arg.data_ptr(),
+                                               _rt.stream_handle(dev)), "p2n_group_max_cm")
+            ctx.save_for_backward(x_cm, ws, arg, *params)
+            return _from_cm(mx, B, L // group)
+        ctx.save_for_backward(x_cm, ws, None, *params)
         return _from_cm(out_cm, B, L)
 
     @staticmethod
@@ -219,13 +232,21 @@ class _SharedMLPTrainFn(torch.autograd.Function):
                                "(retain_graph is not supported on this path)")
         ctx.done = True
         L_ = _lib.lib()
-        dims, last_plain, B, L, P, Ppad, table = ctx.meta
-        x_cm, ws = ctx.saved_tensors[0], ctx.saved_tensors[1]
-        params = ctx.saved_tensors[2:]
+        dims, last_plain, B, L, P, Ppad, table, group = ctx.meta
+        x_cm, ws, arg = ctx.saved_tensors[0], ctx.saved_tensors[1], ctx.saved_tensors[2]
+        params = ctx.saved_tensors[3:]
         nl = len(dims) - 1
         dev = x_cm.device
         arr = (ctypes.c_int * len(dims))(*dims)
-        dout_cm = _to_cm(_rt.require_cuda_f32(gout, "grad_output"), Ppad)      # a private copy: the call overwrites it
+        if group:
+            G = P // group
+            g_cm = _to_cm(_rt.require_cuda_f32(gout, "grad_output"), G)        # (B,C,M) -> (C, B*M)
+            dout_cm = torch.empty((dims[-1], Ppad), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L_.p2n_group_max_cm_bwd(g_cm.data_ptr(), arg.data_ptr(), dims[-1], G, group, Ppad, dout_cm.data_ptr(),
+                                                   _rt.stream_handle(dev)), "p2n_group_max_cm_bwd")
+        else:
+            dout_cm = _to_cm(_rt.require_cuda_f32(gout, "grad_output"), Ppad)  # a private copy: the call overwrites it
         grads = [torch.empty_like(p) for p in params]
         gtab, gi = [], 0
         for l in range(nl):
@@ -245,13 +266,14 @@ class _SharedMLPTrainFn(torch.autograd.Function):
                                                  gptrs, _rt.ptr(dx_cm), ws.data_ptr(), ws.numel(), _rt.stream_handle(dev)),
                        "p2n_mlp_train_backward")
         dx = _from_cm(dx_cm, B, L) if need_dx else None
-        return (dx, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, *grads)
 
 
-def shared_mlp_train(net: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+def shared_mlp_train(net: nn.Sequential, x: torch.Tensor, group: int = 0) -> torch.Tensor:
     """Train-mode forward, with autograd, of nn.Sequential(Conv1d(k=1), BatchNorm1d, ReLU, ... [, Conv1d(k=1)]) on a
     GPU tensor (B,C,L) through p2n_mlp_train_forward / p2n_mlp_train_backward; BatchNorm buffers are updated as
-    nn.BatchNorm1d does in train() mode."""
+    nn.BatchNorm1d does in train() mode.  group > 0: followed by the maximum over groups of `group` consecutive
+    columns -> (B, Cout, L // group), i.e. net(x).view(B, Cout, L // group, group).max(dim=3).values."""
     mods, i = list(net), 0
     if not mods or not isinstance(mods[0], nn.Conv1d):
         raise NotImplementedError("a shared MLP starts with a Conv1d")
@@ -283,7 +305,7 @@ def shared_mlp_train(net: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     if len({bn.momentum for bn in bns}) > 1:
         raise NotImplementedError("the BatchNorm layers of one shared MLP must share one momentum")
     momentum = bns[0].momentum if bns else 0.1
-    y = _SharedMLPTrainFn.apply(x, tuple(dims), last_plain, momentum, tuple(buffers), *params)
+    y = _SharedMLPTrainFn.apply(x, tuple(dims), last_plain, momentum, tuple(buffers), int(group), *params)
     with torch.no_grad():
         for bn in bns:
             bn.num_batches_tracked += 1
@@ -321,8 +343,8 @@ class SharedMLP(nn.Module):
                 i += 1
         return out
 
-    def _forward_train(self, x):
-        return shared_mlp_train(self.net, x)
+    def _forward_train(self, x, group: int = 0):
+        return shared_mlp_train(self.net, x, group)
 
     def forward(self, x):                                   # (B,C,L)
         if not x.is_cuda:
@@ -406,8 +428,7 @@ class SetAbstraction(nn.Module):
                     _lib.check(L.p2n_sa_group(xyz.data_ptr(), new_xyz.data_ptr(), None, gidx.data_ptr(), B, 0, N, M, ns,
                                               rel.data_ptr(), _rt.stream_handle(xyz.device)), "p2n_sa_group")
                 grouped = rel if feat is None else torch.cat([rel, ops.group_gather(feat.contiguous(), gidx)], dim=1)
-                y = self.mlp(grouped.view(B, C + 3, M * ns)).view(B, -1, M, ns)
-                return new_xyz, y.max(dim=3).values
+                return new_xyz, self.mlp._forward_train(grouped.view(B, C + 3, M * ns), group=ns)   # MLP + max over the group
             grouped = torch.empty((B, C + 3, M, ns), dtype=torch.float32, device=xyz.device)
             with torch.cuda.device(xyz.device):
                 _lib.check(L.p2n_sa_group(xyz.data_ptr(), new_xyz.data_ptr(), _rt.ptr(feat), gidx.data_ptr(), B, C, N, M,

@@ -206,3 +206,35 @@ def test_eval_images_follow_running_statistics_updated_without_an_optimizer_step
             got = gpu.eval()(x.cuda())
         assert _rel(got, want) <= 2e-5, f"{type(ref).__name__}: stale eval image ({_rel(got, want):.2e})"
         assert _rel(got, a) > 1e-3                       # the statistics did move
+
+
+@pytest.mark.parametrize("C,G,ns,pad", [(3, 10, 8, 0), (64, 2048, 32, 0), (5, 37, 16, 40), (2, 9, 64, 64), (7, 50, 5, 2), (1, 1, 1, 3)])
+def test_group_max_on_channel_major_rows_and_its_backward(C, G, ns, pad):
+    """p2n_group_max_cm / p2n_group_max_cm_bwd (the set-abstraction levels' max over a group in training, taken on the
+    channel-major output of the train-mode shared MLP) against torch: values and first arg-max positions bit-exact on
+    rows with negative values, exact ties and an all-equal group; the backward equals autograd's routing and zeroes
+    the pad columns."""
+    from pointcloudsegmentation_amd import _lib, runtime as _rt
+    L = _lib.lib()
+    ld = (G * ns + pad + 3) // 4 * 4
+    g = torch.Generator().manual_seed(C * 131 + ns)
+    x = torch.randn(C, ld, generator=g)
+    x[:, :G * ns].view(C, G, ns)[:, ::3, :] = x[:, :G * ns].view(C, G, ns)[:, ::3, :].round()      # exact ties
+    x[0, :ns] = 0.25                                                                                # an all-equal group
+    xg = x.cuda()
+    out = torch.empty(C, G, device="cuda")
+    arg = torch.empty(C, G, dtype=torch.uint8, device="cuda")
+    _lib.check(L.p2n_group_max_cm(xg.data_ptr(), C, ld, G, ns, out.data_ptr(), arg.data_ptr(), _rt.stream_handle(xg.device)),
+               "p2n_group_max_cm")
+    v = x[:, :G * ns].view(C, G, ns)
+    want = v.max(dim=2).values
+    first = (v == want.unsqueeze(2)).to(torch.uint8).argmax(dim=2)
+    assert torch.equal(out.cpu(), want)
+    assert torch.equal(arg.cpu().long(), first)
+    gout = torch.randn(C, G, generator=g)
+    din = torch.full((C, ld), float("nan"), device="cuda")
+    _lib.check(L.p2n_group_max_cm_bwd(gout.cuda().data_ptr(), arg.data_ptr(), C, G, ns, ld, din.data_ptr(),
+                                      _rt.stream_handle(xg.device)), "p2n_group_max_cm_bwd")
+    ref = torch.zeros(C, ld)
+    ref[:, :G * ns].view(C, G, ns).scatter_(2, first.unsqueeze(2), gout.unsqueeze(2))
+    assert torch.equal(din.cpu(), ref)
