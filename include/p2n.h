@@ -173,7 +173,8 @@ int p2n_train_backward_x3(const float *x, const float *gemb, int B, int N, int f
  * place (momentum in [0,1], unbiased variance, eps 1e-5).  The workspace keeps the pre-BatchNorm activations and
  * must stay untouched until p2n_mlp_train_backward, which takes dout_cm = dL/d out_cm (OVERWRITTEN) and fills
  * grads_host (HOST array of 4 DEVICE pointers per layer: dW, dbias, dgamma, dbeta; the last two NULL for a plain
- * last layer) and dx_cm = dL/d x_cm (dims[0], Ppad), or skips the input gradient when dx_cm is NULL. */
+ * last layer) and dx_cm = dL/d x_cm (dims[0], Ppad), or skips the input gradient when dx_cm is NULL. * momentum < 0: eval-mode BatchNorm under autograd (running statistics used and left untouched), as in
+ * p2n_train_forward. */
 size_t p2n_mlp_train_workspace_bytes(long P, int nl, const int *dims, int last_plain);
 int p2n_mlp_train_forward(const float *x_cm, long P, int nl, const int *dims, int last_plain,
                           const void *const *params_host, float momentum, float *out_cm,

@@ -1674,7 +1674,9 @@ extern "C" size_t p2n_mlp_train_workspace_bytes(long P, int nl, const int *dims,
 // x_cm (dims[0], Ppad) -> out_cm (dims[nl], Ppad), Ppad = P rounded up to 128 (pad columns of x_cm must be finite;
 // they never reach a statistic or a gradient).  params_host: HOST array of 6 DEVICE pointers per layer
 // (W (cout,cin), b, gamma, beta, running_mean, running_var; the last four NULL for a plain last layer);
-// running statistics are updated in place with `momentum` (unbiased variance, as torch).  eps is 1e-5.
+// running statistics are updated in place with `momentum` (unbiased variance, as torch); momentum < 0 = eval-mode
+// BatchNorm for a differentiable forward: the layers normalise with the running statistics and leave them untouched,
+// the backward is that of a per-channel affine map (the bias in front of a BatchNorm then has a gradient).  eps is 1e-5.
 // The workspace keeps what p2n_mlp_train_backward needs and must stay untouched until then.
 extern "C" int p2n_mlp_train_forward(const float *x_cm, long P, int nl, const int *dims, int last_plain,
                                      const void *const *params_host, float momentum, float *out_cm, void *workspace,
@@ -1682,7 +1684,8 @@ extern "C" int p2n_mlp_train_forward(const float *x_cm, long P, int nl, const in
     Mlp m;
     TRY(mlp_init(m, "p2n_mlp_train_forward", P, nl, dims, last_plain));
     P2N_REQUIRE(x_cm && params_host && out_cm, "p2n_mlp_train_forward: null pointer");
-    P2N_REQUIRE(momentum >= 0.f && momentum <= 1.f, "p2n_mlp_train_forward: momentum %g not in [0,1]", momentum);
+    P2N_REQUIRE(momentum <= 1.f, "p2n_mlp_train_forward: momentum %g not in [0,1] (negative: eval-mode statistics)", momentum);
+    const bool eval_stats = momentum < 0.f;   // eval-mode BatchNorm under autograd: running statistics, left untouched
     const size_t need = mlp_carve(m, nullptr);
     if (!workspace || workspace_bytes < need) {
         p2n_set_error("p2n_mlp_train_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
@@ -1698,7 +1701,7 @@ extern "C" int p2n_mlp_train_forward(const float *x_cm, long P, int nl, const in
                     "p2n_mlp_train_forward: null parameter pointer in layer %d", l);
     }
     hipStream_t s = (hipStream_t)stream_;
-    P2N_CHECK_HIP(hipMemsetAsync(m.mode, 0, sizeof(int), s));
+    P2N_CHECK_HIP(hipMemsetAsync(m.mode, eval_stats ? 1 : 0, sizeof(int), s));   // the backward reads it on the device
     const int P32 = (int)P, Pp = (int)m.Ppad;
     for (int l = 0; l < nl; ++l) {
         const bool plain = m.last_plain && l == nl - 1;
@@ -1710,12 +1713,17 @@ extern "C" int p2n_mlp_train_forward(const float *x_cm, long P, int nl, const in
         if (l == 0) { a.in0 = x_cm; TRY((launch_layer<LD_PLAIN, false>(a, s))); }
         else { a.in0 = m.z[l - 1]; a.tab = m.ftab[l - 1]; TRY((launch_layer<LD_BNRELU, false>(a, s))); }
         if (plain) break;
-        StatArgs st = {};
-        st.z = m.z[l]; st.part = m.part; st.rows = rows; st.P = P32; st.Ppad = Pp; st.S = STAT_S; st.N = P32;
-        hipLaunchKernelGGL(p2n_row_stats_kernel<ST_FWD>, dim3(rows, STAT_S), dim3(256), 0, s, st);
-        P2N_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(p2n_bn_finalize_fwd_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, m.part, m.z[l], Pp, rows, STAT_S,
-                           P32, m.gamma[l], m.beta[l], m.rmean[l], m.rvar[l], momentum, m.ftab[l]);
+        if (eval_stats) {
+            hipLaunchKernelGGL(p2n_bn_eval_tab_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, rows, m.gamma[l], m.beta[l], m.rmean[l],
+                               m.rvar[l], m.ftab[l]);
+        } else {
+            StatArgs st = {};
+            st.z = m.z[l]; st.part = m.part; st.rows = rows; st.P = P32; st.Ppad = Pp; st.S = STAT_S; st.N = P32;
+            hipLaunchKernelGGL(p2n_row_stats_kernel<ST_FWD>, dim3(rows, STAT_S), dim3(256), 0, s, st);
+            P2N_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(p2n_bn_finalize_fwd_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, m.part, m.z[l], Pp, rows, STAT_S,
+                               P32, m.gamma[l], m.beta[l], m.rmean[l], m.rvar[l], momentum, m.ftab[l]);
+        }
         P2N_CHECK_HIP(hipGetLastError());
         if (l == nl - 1) {
             hipLaunchKernelGGL(p2n_bnrelu_apply_kernel, dim3((unsigned)((m.Ppad / 4 + 255) / 256), rows), dim3(256), 0, s,

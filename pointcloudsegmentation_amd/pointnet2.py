@@ -269,11 +269,12 @@ class _SharedMLPTrainFn(torch.autograd.Function):
         return (dx, None, None, None, None, None, *grads)
 
 
-def shared_mlp_train(net: nn.Sequential, x: torch.Tensor, group: int = 0) -> torch.Tensor:
+def shared_mlp_train(net: nn.Sequential, x: torch.Tensor, group: int = 0, eval_stats: bool = False) -> torch.Tensor:
     """Train-mode forward, with autograd, of nn.Sequential(Conv1d(k=1), BatchNorm1d, ReLU, ... [, Conv1d(k=1)]) on a
     GPU tensor (B,C,L) through p2n_mlp_train_forward / p2n_mlp_train_backward; BatchNorm buffers are updated as
     nn.BatchNorm1d does in train() mode.  group > 0: followed by the maximum over groups of `group` consecutive
-    columns -> (B, Cout, L // group), i.e. net(x).view(B, Cout, L // group, group).max(dim=3).values."""
+    columns -> (B, Cout, L // group), i.e. net(x).view(B, Cout, L // group, group).max(dim=3).values.
+    eval_stats: eval-mode BatchNorm under autograd -- running statistics used, nothing updated."""
     mods, i = list(net), 0
     if not mods or not isinstance(mods[0], nn.Conv1d):
         raise NotImplementedError("a shared MLP starts with a Conv1d")
@@ -288,7 +289,7 @@ def shared_mlp_train(net: nn.Sequential, x: torch.Tensor, group: int = 0) -> tor
             bn = mods[i + 1]
             if not (i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)):
                 raise NotImplementedError("every BatchNorm1d of a GPU shared MLP is followed by a ReLU")
-            if bn.momentum is None:
+            if bn.momentum is None and not eval_stats:
                 raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not implemented on the GPU path")
             if abs(bn.eps - 1e-5) > 1e-12 or not bn.affine or not bn.track_running_stats:
                 raise NotImplementedError("the GPU shared MLP needs BatchNorm1d(eps=1e-5, affine=True, track_running_stats=True)")
@@ -302,6 +303,8 @@ def shared_mlp_train(net: nn.Sequential, x: torch.Tensor, group: int = 0) -> tor
             last_plain = True
             buffers += [None, None]
             i += 1
+    if eval_stats:
+        return _SharedMLPTrainFn.apply(x, tuple(dims), last_plain, -1.0, tuple(buffers), int(group), *params)
     if len({bn.momentum for bn in bns}) > 1:
         raise NotImplementedError("the BatchNorm layers of one shared MLP must share one momentum")
     momentum = bns[0].momentum if bns else 0.1
@@ -344,16 +347,17 @@ class SharedMLP(nn.Module):
         return out
 
     def _forward_train(self, x, group: int = 0):
-        return shared_mlp_train(self.net, x, group)
+        """with autograd: batch statistics in train() mode, the running statistics (left untouched) in eval() mode"""
+        return shared_mlp_train(self.net, x, group, eval_stats=not self.training)
+
+    def needs_autograd(self, x) -> bool:
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def forward(self, x):                                   # (B,C,L)
         if not x.is_cuda:
             return self.net(x)
-        if self.training:
+        if self.training or self.needs_autograd(x):
             return self._forward_train(x)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("differentiating through eval-mode BatchNorm is not implemented for the hierarchical "
-                                      "levels on the GPU: call train(), or eval() under torch.no_grad()")
         L = _lib.lib()
         x = _rt.require_cuda_f32(x, "x")
         B, _, n = x.shape
@@ -420,7 +424,7 @@ class SetAbstraction(nn.Module):
             new_xyz = ops.group_gather(xyz_t, fidx.unsqueeze(2)).squeeze(3).transpose(1, 2).contiguous()
             gidx = ops.ball_query(xyz, new_xyz, self.radius, ns)
             C = 0 if feat is None else feat.size(1)
-            if self.training and torch.is_grad_enabled():
+            if torch.is_grad_enabled() and (self.training or self.mlp.needs_autograd(xyz if feat is None else feat)):
                 # differentiable composition: relative coordinates (no gradient) ++ gathered features (p2n_group_gather
                 # with its scatter-add adjoint), train-mode shared MLP, max over the group through autograd
                 rel = torch.empty((B, 3, M, ns), dtype=torch.float32, device=xyz.device)

@@ -102,9 +102,6 @@ def forward_train(model, x):
     """Train-mode forward of a Point2Net on a GPU tensor (B,N,F) -> (B,N,E) with autograd."""
     eval_stats = not model.training   # eval-mode BatchNorm under autograd: running statistics, left untouched
     if x.requires_grad:
-        if eval_stats:
-            raise NotImplementedError("a gradient for the input points through eval-mode BatchNorm is not implemented on "
-                                      "the HIP path (train() mode provides it)")
         return forward_train_with_input_grad(model, x)
     x = _rt.require_cuda_f32(x, "x")
     if not eval_stats and x.size(0) * x.size(1) < 2:
@@ -130,30 +127,31 @@ def forward_train(model, x):
 
 
 def encode_train(encoder, x):
-    """PointNet2Encoder alone under autograd / in train() mode on a GPU tensor (B,N,F) -> (f1, f2, f3, global_f)
-    (reference point2net.py:36-48): the three blocks run as train-mode shared MLPs (p2n_mlp_train_forward /
-    p2n_mlp_train_backward, which also return the gradient w.r.t. the input points), the global max through autograd."""
+    """PointNet2Encoder alone under autograd (train() or eval() mode) on a GPU tensor (B,N,F) -> (f1, f2, f3, global_f)
+    (reference point2net.py:36-48): the three blocks run as differentiable shared MLPs (p2n_mlp_train_forward /
+    p2n_mlp_train_backward, which also return the gradient w.r.t. the input points; batch statistics in train() mode,
+    the running statistics in eval() mode), the global max through autograd."""
     from .pointnet2 import shared_mlp_train   # noqa: WPS433
-    if not encoder.training:
-        raise NotImplementedError("autograd through eval-mode BatchNorm of a bare PointNet2Encoder is not implemented on "
-                                  "the HIP path: call train(), use torch.no_grad(), or differentiate through Point2Net")
+    ev = not encoder.training           # eval() under autograd: running statistics, left untouched
     x = _rt.require_cuda_f32(x, "x")
-    if x.size(0) * x.size(1) < 2:
+    if not ev and x.size(0) * x.size(1) < 2:
         raise ValueError("Expected more than 1 value per channel when training")
     xt = x.transpose(1, 2)
-    f1 = shared_mlp_train(encoder.mlp1, xt)
-    f2 = shared_mlp_train(encoder.mlp2, f1)
-    f3 = shared_mlp_train(encoder.mlp3, f2)
-    encoder._cache.key = None           # running statistics changed behind the packed eval image's back
+    f1 = shared_mlp_train(encoder.mlp1, xt, eval_stats=ev)
+    f2 = shared_mlp_train(encoder.mlp2, f1, eval_stats=ev)
+    f3 = shared_mlp_train(encoder.mlp3, f2, eval_stats=ev)
+    if not ev:
+        encoder._cache.key = None       # running statistics changed behind the packed eval image's back
     return f1, f2, f3, torch.max(f3, dim=2)[0]
 
 
 def forward_train_with_input_grad(model, x):
-    """Point2Net in train() mode when the input points need a gradient: the reference's op sequence
+    """Point2Net (train() or eval() mode) when the input points need a gradient: the reference's op sequence
     (point2net.py:75-87) on train-mode shared MLPs, which produce d/dx; the fused p2n_train_forward path does not."""
     from .pointnet2 import shared_mlp_train   # noqa: WPS433
     f1, f2, f3, g = encode_train(model.encoder, x)
     combined = torch.cat([f3, g.unsqueeze(2).expand(-1, -1, f3.size(2))], dim=1)
-    emb = shared_mlp_train(model.embedding_net, combined).transpose(1, 2)
-    model._cache.key = None
+    emb = shared_mlp_train(model.embedding_net, combined, eval_stats=not model.training).transpose(1, 2)
+    if model.training:
+        model._cache.key = None
     return emb

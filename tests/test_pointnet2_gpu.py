@@ -73,8 +73,10 @@ def test_point2net_sa_end_to_end():
     assert got.shape == (2, 2048, 64)
     assert_close_to_max(got.cpu().numpy(), want.numpy(), 2e-5, "Point2NetSA embeddings (fused levels)")
     assert_close_to_max(unf.cpu().numpy(), want.numpy(), 2e-5, "Point2NetSA embeddings (per-operator path)")
-    with pytest.raises(NotImplementedError):         # autograd through eval-mode BatchNorm: not on this path
-        m(x.cuda().requires_grad_(True))
+    # eval() with autograd enabled: differentiable per-operator path on the running statistics (values: the training tests)
+    y = m(x.cuda().requires_grad_(True))
+    assert y.requires_grad and y.shape == (2, 2048, 64)
+    assert_close_to_max(y.detach().cpu().numpy(), want.numpy(), 2e-5, "Point2NetSA embeddings (eval mode under autograd)")
 
 
 # ---------------------------------------------------------------- fused levels (p2n_sa_level / p2n_fp_level)
