@@ -136,7 +136,17 @@ def fps_leg(device):
         e1.record()
         torch.cuda.synchronize(device)
         return e0.elapsed_time(e1)
+    # Floor of the round design at this shape: per accepted sample the update's instruction issue on
+    # one SIMD (10 points per lane = 5 point pairs x 10 packed instructions x 4 cycles) plus one exchange per round -- one
+    # producer->consumer hop inside an XCD, 530 shader cycles (profiles/r03_g_micro_fps_handoff.txt: 221-254 ns) -- spread
+    # over the 8.6 samples a round accepts here (profiles/r03_h_fps_phase_clocks.txt), at the 2.35 GHz the kernel runs at.
+    floor_us = (5 * 10 * 4 + 530 / 8.6) / 2350.0
     return {"ms_per_40k_scene": ms, "npoint": npoint, "us_per_sample": 1e3 * ms / npoint,
+            "floor_us_per_sample": floor_us, "achieved_fraction_of_floor": floor_us / (1e3 * ms / npoint),
+            "floor_model": "update issue (5 point pairs x 10 packed instructions x 4 cycles per sample) + one in-XCD hand-off "
+                           "(530 cycles, profiles/r03_g_micro_fps_handoff.txt) per round of 8.6 samples "
+                           "(profiles/r03_h_fps_phase_clocks.txt) at 2.35 GHz; publish, poll skew and the decision are what "
+                           "the achieved figure adds",
             "ms_per_40k_scene_batch_of_8": ms8 / 8,
             "ms_16x8192_to_2048": once(16, 8192, 2048, 11),             # the hierarchical sibling's first level
             "ms_1m_to_16384": once(1, 1_000_000, 16384, 4, "lidar"),    # BASELINE.json configs[4]
