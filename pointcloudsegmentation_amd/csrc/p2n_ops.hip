@@ -11,13 +11,13 @@
 
 // Tuning overrides for the sweep tools (tools/fps_sweep.py, tools/sweep_gather.sh), read from the
 // environment once per process: 0 / unset = the built-in choice.
-struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd, fps_prune, fps_pw, fps_rounds, fps_pd; };
+struct P2nTuning { int fps_g, gl_ch, gl_threads, gl_split, gl_off, fps_t, fps_spin, fps_fault, fps_noxcd, fps_prune, fps_pw, fps_rounds, fps_pd, fps_exp; };
 static const P2nTuning &p2n_tuning() {
     static const P2nTuning t = [] {
         auto num = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
         return P2nTuning{num("P2N_FPS_G"), num("P2N_GL_CH"), num("P2N_GL_THREADS"), num("P2N_GL_SPLIT"),
                          getenv("P2N_GL_OFF") ? 1 : 0, num("P2N_FPS_T"), num("P2N_FPS_SPIN"),
-                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD"), num("P2N_FPS_PRUNE"), num("P2N_FPS_PW"), num("P2N_FPS_ROUNDS"), num("P2N_FPS_PD")};
+                         num("P2N_FPS_FAULT"), num("P2N_FPS_NOXCD"), num("P2N_FPS_PRUNE"), num("P2N_FPS_PW"), num("P2N_FPS_ROUNDS"), num("P2N_FPS_PD"), num("P2N_FPS_EXP")};
     }();
     return t;
 }
@@ -97,6 +97,7 @@ struct FpsArgs {
     int N, M, G, chunk, start_idx, b0, spin_limit;
     int xcd_mode, nb;   // xcd_mode: grid = 8*G*ceil(nb/8) blocks, a cloud's workgroups share blockIdx % 8 (one XCD under round-robin dealing)
     int poll_delay;     // s_sleep units between a round's publish and its first poll (rounds kernels)
+    int exp;            // P2N_FPS_TIMING builds only: switch parts of the decision off to time them (results are then wrong)
     int fault_it;       // test hook (P2N_FPS_FAULT=k): the cloud's last workgroup skips its publish in iteration k; 0 = off
 };
 
@@ -362,20 +363,39 @@ __device__ __forceinline__ bool fr_poll(const u64 *rec, unsigned tag, fr_u32x4 &
 // distances (a serial count over the candidate mask; rare).  acc lanes hold an accepted sample's coordinates, rank and index.
 struct FrDecision { bool acc; unsigned rank; unsigned klo; float x, y, z; };
 // R records per lane (record lane + 64 r): clusters of up to 64 R members.
+// the instruction itself: __ballot() takes an int and costs a select and a compare on top
+__device__ __forceinline__ u64 fr_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// best key (whi, wlo) of a wave and the second largest running minimum among its points: lanes at the top distance hand in
+// their own second best, everybody else their best; several lanes at the top distance make the second best that distance
+// itself.  The two reductions behind whi do not depend on each other, so their DPP chains interleave.
+__device__ __forceinline__ void fr_wave_top2(unsigned hi, unsigned lo, unsigned sec, unsigned &whi, unsigned &wlo, unsigned &d2) {
+    whi = wave_max_u32(hi);
+    const bool top = hi == whi;
+    const u64 tm = fr_ballot(top);
+    wlo = wave_max_u32(top ? lo : 0u);
+    const unsigned o = wave_max_u32(top ? sec : hi);
+    d2 = (tm & (tm - 1)) ? whi : o;
+}
+
 template <int R>
 __device__ __forceinline__ FrDecision fr_decide(const bool (&mine)[R], const unsigned (&khi)[R], const unsigned (&klo)[R], const float (&x)[R],
                                                 const float (&y)[R], const float (&z)[R], const unsigned (&d2v)[R], const int room, float4 *rec,
-                                                u64 *reck, const int lane) {
+                                                u64 *reck, const int lane, const int exp = 0) {
     FrDecision D;
     unsigned dmax = 0u;
 #pragma unroll
     for (int r = 0; r < R; ++r) dmax = (mine[r] && d2v[r] > dmax) ? d2v[r] : dmax;
+#ifdef P2N_FPS_TIMING
+    const unsigned S = (exp & 2) ? 0x3c000000u : wave_max_u32(dmax);
+#else
     const unsigned S = wave_max_u32(dmax);
+#endif
     bool cand[R];
     u64 cmask[R];
     int n = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) { cand[r] = mine[r] && khi[r] > S; cmask[r] = __ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
+    for (int r = 0; r < R; ++r) { cand[r] = mine[r] && khi[r] > S; cmask[r] = fr_ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
     if (n > 16) {
         // keep the candidates with the 16 largest distances (a set closed from the top, ties kept or dropped together:
         // the accepted samples are a prefix of the key order anyway)
@@ -395,7 +415,7 @@ __device__ __forceinline__ FrDecision fr_decide(const bool (&mine)[R], const uns
         }
         n = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { cand[r] = cand[r] && ge[r] <= 16u; cmask[r] = __ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
+        for (int r = 0; r < R; ++r) { cand[r] = cand[r] && ge[r] <= 16u; cmask[r] = fr_ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
     }
     if (n == 0) {   // the largest distance ties somebody's second best (or 17 bests tie): only the overall best is provably next
         unsigned hm = 0u;
@@ -407,9 +427,11 @@ __device__ __forceinline__ FrDecision fr_decide(const bool (&mine)[R], const uns
         for (int r = 0; r < R; ++r) lm = (mine[r] && khi[r] == ahi && klo[r] > lm) ? klo[r] : lm;
         const unsigned alo = wave_max_u32(lm);
 #pragma unroll
-        for (int r = 0; r < R; ++r) { cand[r] = mine[r] && khi[r] == ahi && klo[r] == alo; cmask[r] = __ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
+        for (int r = 0; r < R; ++r) { cand[r] = mine[r] && khi[r] == ahi && klo[r] == alo; cmask[r] = fr_ballot(cand[r]); n += (int)__builtin_popcountll(cmask[r]); }
     }
-    // candidates compacted into LDS in (r, lane) order
+    // candidates compacted into LDS in (r, lane) order; the entries behind them are zero (key 0 is never "earlier", distance
+    // 0 is never undercut), so the pair evaluation below needs no validity tests
+    if (lane < 16) { rec[lane] = make_float4(0.f, 0.f, 0.f, 0.f); reck[lane] = 0ull; }
     int off = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -422,7 +444,7 @@ __device__ __forceinline__ FrDecision fr_decide(const bool (&mine)[R], const uns
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int i = lane & 15, jb = lane >> 4;
-    // all reads first (entries past n are stale and masked below), so that their latencies overlap
+    // all reads first, so that their latencies overlap
     const float4 Ri = rec[i];
     const u64 ki = reck[i];
     float4 Rj[4];
@@ -431,19 +453,22 @@ __device__ __forceinline__ FrDecision fr_decide(const bool (&mine)[R], const uns
     for (int pass = 0; pass < 4; ++pass) { Rj[pass] = rec[jb + 4 * pass]; kj[pass] = reck[jb + 4 * pass]; }
     const u64 col = 0x0001000100010001ull << i;
     const unsigned colo = (unsigned)col, cohi = (unsigned)(col >> 32);
-    const bool iv = i < n;
     u64 many = 0ull;
     unsigned rank = 0u;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
+#ifdef P2N_FPS_TIMING
+        if (4 * pass < n && !(exp & 1)) {
+#else
         if (4 * pass < n) {   // uniform
-            const bool bigger = iv && jb + 4 * pass < n && kj[pass] > ki;
+#endif
+            const bool bigger = kj[pass] > ki;
             const float dd = sqdist3(Ri.x, Ri.y, Ri.z, Rj[pass].x, Rj[pass].y, Rj[pass].z);   // the update's own expression
             // a sample with a non-finite coordinate never clears its own running minimum (p - p is NaN): the
             // sequential algorithm picks it again at once, so nothing may follow it within a round
             const bool sticky = !__builtin_isfinite((Rj[pass].x + Rj[pass].y) + Rj[pass].z);
-            const u64 mb = __ballot(bigger);
-            many |= __ballot(bigger && (dd < Ri.w || sticky));
+            const u64 mb = fr_ballot(bigger);
+            many |= fr_ballot(bigger && (dd < Ri.w || sticky));
             rank += (unsigned)__builtin_popcount((unsigned)mb & colo) + (unsigned)__builtin_popcount((unsigned)(mb >> 32) & cohi);
         }
     }
@@ -574,18 +599,16 @@ __global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {   // R: 
         const unsigned hi = (unsigned)(tk[0] >> 32);
         const unsigned lo = inv0 - (unsigned)(T * (63 - (int)bcode));
         // ---- wave: best key, and the second best = max over lanes of (the winner lane's second, everybody else's best)
-        const unsigned whi = wave_max_u32(hi);
-        const unsigned wlo = wave_max_u32(hi == whi ? lo : 0u);
-        const unsigned wsec = wave_max_u32((hi == whi && lo == wlo) ? sec : hi);
+        unsigned whi, wlo, wsec;
+        fr_wave_top2(hi, lo, sec, whi, wlo, wsec);
         if (lane == 0) { wv[wave][0] = whi; wv[wave][1] = wlo; wv[wave][2] = wsec; }
         __syncthreads();
         if (wave == 0) {
             const int nbuf = buf ^ 1;
             // workgroup: the same combination over the four waves
             const unsigned h4 = lane < NWV ? wv[lane][0] : 0u, l4 = lane < NWV ? wv[lane][1] : 0u, s4 = lane < NWV ? wv[lane][2] : 0u;
-            const unsigned k1hi = wave_max_u32(h4);
-            const unsigned k1lo = wave_max_u32(h4 == k1hi ? l4 : 0u);
-            const unsigned d2 = wave_max_u32((lane < NWV && h4 == k1hi && l4 == k1lo) ? s4 : h4);
+            unsigned k1hi, k1lo, d2;
+            fr_wave_top2(h4, l4, s4, k1hi, k1lo, d2);   // lanes past the last wave hand in zeros
             const int li = (int)(0xFFFFFFFFu - k1lo);
             u64 *slot = ring + (long)(round % FR_RING) * A.G * FR_SLOT;
             const unsigned tag = fr_tag(round);
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {   // R: 
             const FrDecision D = fr_decide<R>(mine, khi, klo, cx_, cy_, cz_, d2v, room, rec, reck, lane);
             const int widx = (int)(0xFFFFFFFFu - D.klo);
             int m = (int)__builtin_popcountll(__ballot(D.acc));
-            if (!ok || m < 1 || __any(D.acc && (widx < 0 || widx >= A.N))) m = -1;
+            if (!ok || m < 1) m = -1;
             if (D.acc && m > 0) {
                 wl[nbuf][D.rank][0] = D.x; wl[nbuf][D.rank][1] = D.y; wl[nbuf][D.rank][2] = D.z; wl[nbuf][D.rank][3] = 0.f;
                 if (g == 0) A.idx[(long)b * A.M + it + (int)D.rank] = widx;
@@ -771,9 +794,8 @@ __global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {
         }
         const unsigned hi = (unsigned)(tk[0] >> 32);
         const unsigned lo = inv0 - (unsigned)(T * (63 - (int)bcode));
-        const unsigned k1hi = wave_max_u32(hi);
-        const unsigned k1lo = wave_max_u32(hi == k1hi ? lo : 0u);
-        const unsigned d2 = wave_max_u32((hi == k1hi && lo == k1lo) ? sec : hi);
+        unsigned k1hi, k1lo, d2;
+        fr_wave_top2(hi, lo, sec, k1hi, k1lo, d2);
         FR_T(2);
         const int li = (int)(0xFFFFFFFFu - k1lo);
         u64 *slot = ring + (long)(round % FR_RING) * A.G * FR_SLOT;
@@ -802,12 +824,12 @@ __global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {
         const float x1[1] = {__uint_as_float(ra[2])}, y1[1] = {__uint_as_float(rc[0])}, z1[1] = {__uint_as_float(rc[2])};
         int room = A.M - it;
         if (A.fault_it > 0 && it <= A.fault_it && room > A.fault_it + 1 - it) room = A.fault_it + 1 - it;
-        const FrDecision D = fr_decide<1>(mine1, khi1, klo1, x1, y1, z1, d2v1, room, rec, reck, lane);
+        const FrDecision D = fr_decide<1>(mine1, khi1, klo1, x1, y1, z1, d2v1, room, rec, reck, lane, A.exp);
         x = D.x; y = D.y; z = D.z;
         const int widx = (int)(0xFFFFFFFFu - D.klo);
         am = __ballot(D.acc);
         const int m = (int)__builtin_popcountll(am);
-        if (!ok || m < 1 || __any(D.acc && (widx < 0 || widx >= A.N))) { dead = true; break; }
+        if (!ok || m < 1) { dead = true; break; }
         if (D.acc && g == 0) A.idx[(long)b * A.M + it + (int)D.rank] = widx;
         it += m;
         FR_T(5);
@@ -1039,7 +1061,7 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
             const FpsWavePlan w = fps_wave_plan(nb, N);
             P2N_REQUIRE(w.G >= 2, "p2n_fps: no wave-cluster plan for N=%d", N);
             FpsArgs a;
-            a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault; a.poll_delay = p2n_tuning().fps_pd;
+            a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault; a.poll_delay = p2n_tuning().fps_pd; a.exp = p2n_tuning().fps_exp;
             a.nb = nb; a.xcd_mode = !p2n_tuning().fps_noxcd && fps_cus() % 8 == 0;
             a.slots = (u64 *)((char *)workspace + 256);
             a.N = N; a.M = M; a.G = w.G; a.chunk = (N + w.G - 1) / w.G; a.start_idx = start_idx; a.b0 = done;
@@ -1082,7 +1104,7 @@ extern "C" int p2n_fps(const float *xyz, int B, int N, int M, int start_idx, int
         }
         P2N_REQUIRE(p.G >= 1, "p2n_fps: N=%d exceeds the on-chip capacity of one launch (%d points)", N, 256 * FPS_LDS_POINTS);
         FpsArgs a;
-        a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault; a.poll_delay = p2n_tuning().fps_pd;
+        a.xyz = xyz; a.idx = idx; a.status = status ? status : (int *)workspace; a.spin_limit = spin; a.fault_it = p2n_tuning().fps_fault; a.poll_delay = p2n_tuning().fps_pd; a.exp = p2n_tuning().fps_exp;
         a.nb = nb;
         // one XCD per cloud when its cluster and the other clouds sharing that XCD fit the XCD's 32 CUs
         a.xcd_mode = p.G > 1 && p.G * ((nb + 7) / 8) <= ncu / 8 && !p2n_tuning().fps_noxcd;
