@@ -227,7 +227,7 @@ int p2n_combine3(const float *g3, const float *a, const float *b, const float *c
  * ties). ----------------------------------------------------------------- */
 
 /* Farthest-point sampling: xyz (B,N,3) -> idx (B,M); first sample = start_idx.
- * Clouds of 4,096 points and more are sampled by a CLUSTER -- single waves (4,096..100,000 points, up to 64 per
+ * Clouds of 4,096 points and more are sampled by a CLUSTER -- single waves (4,096..160,000 points, up to 128 per
  * cloud, kind 1) or 256/1024-thread workgroups (larger clouds, kind 2) -- whose members keep the cloud in registers and
  * exchange records through memory: one exchange per ROUND, and a round accepts every published best that provably is
  * the sequential algorithm's next sample (indices are bit-identical to the one-at-a-time algorithm).  The members of

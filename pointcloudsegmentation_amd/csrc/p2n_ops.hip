@@ -686,8 +686,8 @@ __global__ __launch_bounds__(T) void p2n_fps_rounds_kernel(FpsArgs A) {   // R: 
 // updates its points, reduces, publishes, polls, decides and keeps the accepted samples in the registers it polled them
 // into.  Up to 64 members per cloud (one decision lane each), placed on one XCD, one per SIMD.  More members mean
 // more candidates per round (tools/sim_fps_rounds.py: 7 samples per round at 64 members) and fewer points per lane.
-template <int PPT>
-__global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {
+template <int PPT, int R>
+__global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {   // R: records per decision lane (members <= 64 R)
     constexpr int T = 64;
     static_assert(PPT % 2 == 0, "points are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) float lxyz[];
@@ -730,16 +730,22 @@ __global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {
         u64 *cs = ring + (long)FR_RING * A.G * FR_SLOT;
         const unsigned myx = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 0xF;
         if (lane == 0) __hip_atomic_store(cs + g * FR_SLOT, (1ull << 32) | (u64)myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u64 v = 1ull << 32 | myx;
         int spins = 0;
-        bool ok;
+        bool ok, same;
         for (;;) {
-            if (lane < A.G) v = __hip_atomic_load(cs + lane * FR_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = __all(lane >= A.G || v != 0ull);
+            ok = true; same = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                u64 v = 1ull << 32 | myx;
+                if (lane + 64 * r < A.G) v = __hip_atomic_load(cs + (lane + 64 * r) * FR_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && v != 0ull;
+                same = same && (unsigned)v == myx;
+            }
+            ok = __all(ok);
             if (ok || ++spins > A.spin_limit) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        fast = ok && __all(lane >= A.G || (unsigned)v == myx);
+        fast = ok && __all(same);
         if (!ok) dead = census_dead = true;
     }
     if (g == 0 && lane == 0) A.idx[(long)b * A.M] = A.start_idx;
@@ -807,24 +813,37 @@ __global__ __launch_bounds__(64) void p2n_fps_wave_rounds_kernel(FpsArgs A) {
             fr_publish(slot + g * FR_SLOT, lane, tag, k1hi, k1lo, cxb, cyb, czb, d2, fast);
         }
         FR_T(3);
-        fr_u32x4 ra = {0, 0, 0, 0}, rc = {0, 0, 0, 0};
-        const bool mine = lane < A.G;
+        fr_u32x4 ra[R], rc[R];
+        bool mine[R], ready[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ra[r] = fr_u32x4{0, 0, 0, 0}; rc[r] = fr_u32x4{0, 0, 0, 0}; mine[r] = lane + 64 * r < A.G; ready[r] = !mine[r]; }
         int spins = 0;
-        bool ok, ready = !mine;
+        bool ok;
         for (int d = 0; d < A.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
         for (;;) {
-            if (!ready) ready = fr_poll(slot + lane * FR_SLOT, tag, ra, rc);
-            ok = __all(ready);
+            bool all = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!ready[r]) ready[r] = fr_poll(slot + (lane + 64 * r) * FR_SLOT, tag, ra[r], rc[r]);
+                all = all && ready[r];
+            }
+            ok = __all(all);
             if (ok || ++spins > A.spin_limit) break;
             __builtin_amdgcn_s_sleep(1);
         }
         FR_T(4);
-        const bool mine1[1] = {mine};
-        const unsigned khi1[1] = {mine ? ra[0] : 0u}, klo1[1] = {mine ? ((ra[1] & 0xFFFFu) | (ra[3] << 16)) : 0u}, d2v1[1] = {(rc[1] & 0xFFFFu) | (rc[3] << 16)};
-        const float x1[1] = {__uint_as_float(ra[2])}, y1[1] = {__uint_as_float(rc[0])}, z1[1] = {__uint_as_float(rc[2])};
+        unsigned khi[R], klo[R], d2v[R];
+        float cx_[R], cy_[R], cz_[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            khi[r] = mine[r] ? ra[r][0] : 0u;
+            klo[r] = mine[r] ? ((ra[r][1] & 0xFFFFu) | (ra[r][3] << 16)) : 0u;
+            d2v[r] = (rc[r][1] & 0xFFFFu) | (rc[r][3] << 16);
+            cx_[r] = __uint_as_float(ra[r][2]); cy_[r] = __uint_as_float(rc[r][0]); cz_[r] = __uint_as_float(rc[r][2]);
+        }
         int room = A.M - it;
         if (A.fault_it > 0 && it <= A.fault_it && room > A.fault_it + 1 - it) room = A.fault_it + 1 - it;
-        const FrDecision D = fr_decide<1>(mine1, khi1, klo1, x1, y1, z1, d2v1, room, rec, reck, lane, A.exp);
+        const FrDecision D = fr_decide<R>(mine, khi, klo, cx_, cy_, cz_, d2v, room, rec, reck, lane, A.exp);
         x = D.x; y = D.y; z = D.z;
         const int widx = (int)(0xFFFFFFFFu - D.klo);
         am = __ballot(D.acc);
@@ -851,7 +870,9 @@ static FpsWavePlan fps_wave_plan(int nb, int N) {
     const int ncu = fps_cus();
     const int cap = (ncu / 8) * 4, per = (nb + 7) / 8;
     int G = cap / per;
-    if (G > 64) G = 64;
+    // one cloud per XCD and 50,000 points or more: a member on every SIMD (128: two records per decision lane) -- measured
+    // 60k 1.83 -> 1.63 ms, 100k 2.59 -> 2.04, 150k 2.94 -> 2.28; below, 64 members (40k: 3.29 vs 3.16, 8 x 40k: 0.89 vs 0.94, 8,192: 0.60 vs 0.74)
+    if (G > (N >= 50000 ? 128 : 64)) G = N >= 50000 ? 128 : 64;
     if (const int g = p2n_tuning().fps_g) { if (g >= 2 && g <= G) G = g; }
     while (G > 2 && (N + G - 1) / G < 64) G >>= 1;   // at least one point per lane
     if (G < 2) return w;
@@ -871,18 +892,22 @@ static bool fps_wave_rounds_wanted(int B, int N) {
     if (w.G < 2) return false;
     if (mode == 2) return true;
     // measured (profiles/r03_h_fps_rounds_ab*.txt): below ~4,096 points one workgroup without any exchange is as fast;
-    // beyond ~100,000 a member's 1,500+ points per wave make the update the round, and 256-thread members win
-    return N >= 4096 && N <= 100000 && w.G >= 8;
+    // beyond ~160,000 a member's 1,200+ points per wave make the update the round, and 256-thread members are as fast
+    return N >= 4096 && N <= 160000 && w.G >= 8;
 }
 
-template <int PPT>
-static hipError_t fps_wave_launch(const FpsArgs &a, int nb, hipStream_t s) {
+template <int PPT, int R>
+static hipError_t fps_wave_launch_r(const FpsArgs &a, int nb, hipStream_t s) {
     const size_t lds = (size_t)a.chunk * 12;
     const int ps = p2n_prof_begin(P2N_K_FPS, s);
     const unsigned grid = a.xcd_mode ? 8u * a.G * ((nb + 7) / 8) : (unsigned)(nb * a.G);
-    hipLaunchKernelGGL((p2n_fps_wave_rounds_kernel<PPT>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((p2n_fps_wave_rounds_kernel<PPT, R>), dim3(grid), dim3(64), lds, s, a);
     p2n_prof_end(ps, s);
     return hipGetLastError();
+}
+template <int PPT>
+static hipError_t fps_wave_launch(const FpsArgs &a, int nb, hipStream_t s) {
+    return a.G > 64 ? fps_wave_launch_r<PPT, 2>(a, nb, s) : fps_wave_launch_r<PPT, 1>(a, nb, s);
 }
 
 // bucket-pruned single-workgroup variant (defined behind the Morton sort it builds on)

@@ -71,7 +71,7 @@ def fps_needs_check(B: int, N: int) -> bool:
 
 def fps_needs_whole_chip(B: int, N: int) -> bool:
     """True when the clouds are sampled by clusters of fat workgroups, planned as if they owned every compute unit:
-    run such a call alone (no kernels of other streams beside it).  Wave-member clusters (4,096..100,000 points) are
+    run such a call alone (no kernels of other streams beside it).  Wave-member clusters (4,096..160,000 points) are
     light enough to become resident beside other kernels."""
     return _lib.lib().p2n_fps_cluster_kind(max(B, 1), max(N, 1)) == 2
 

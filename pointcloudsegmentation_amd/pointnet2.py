@@ -558,10 +558,10 @@ class Point2NetSA(nn.Module):
         dev = x.device
         main = torch.cuda.current_stream(dev)
         xyz0 = x[:, :, :3].contiguous()
-        # Clouds sampled by clusters of fat WORKGROUPS (> 100,000 points) are planned as if they owned every CU: beside the
+        # Clouds sampled by clusters of fat WORKGROUPS (> 160,000 points) are planned as if they owned every CU: beside the
         # level kernels of other streams their workgroups may not all be resident and the exchange would time out.  They
         # run the whole forward in order on the caller's stream instead (no overlap, nothing to time out against).
-        # Wave-member clusters (4,096..100,000 points) are a few registers and an LDS sliver per member: they fit beside
+        # Wave-member clusters (4,096..160,000 points) are a few registers and an LDS sliver per member: they fit beside
         # the level kernels and keep the overlap; either kind is checked where the indices have been consumed.
         clusters = ops.fps_needs_check(x.shape[0], x.shape[1])
         if not self.overlap_geometry or ops.fps_needs_whole_chip(x.shape[0], x.shape[1]):

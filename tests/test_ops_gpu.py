@@ -125,7 +125,7 @@ def test_fps_ties_duplicates_and_oversampling():
 def test_fps_edge_cases_default_routing():
     """Exact ties (lattices), duplicates, degenerate extents, ragged member sizes, more samples than distinct points, a NaN
     coordinate, 1..N samples, more clouds than one launch takes: same indices as the oracle (tests/fps_cases.py), with the
-    kernels the library picks by itself (wave clusters for 4,096..100,000 points, 256-thread round clusters above)."""
+    kernels the library picks by itself (wave clusters for 4,096..160,000 points, 256-thread round clusters above)."""
     import fps_cases
     fps_cases.run(small=False)
 
