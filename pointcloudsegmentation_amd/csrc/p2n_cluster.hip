@@ -195,6 +195,7 @@ struct ClArgs {
     const int *act_cnt;     // per 256-point row block (one workgroup): number of active 128-point blocks
     const int *act_list;    // [row block][nb128]: their indices, ascending
     int nb128;
+    unsigned char *hit;     // pass 1 writes [row block][nb128]: 1 where some pair of the two blocks came within the "maybe" threshold
     unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
     // pass 1: undecided pairs are queued per lane ([wave][slot][lane] = partner index) and decided by
     // cl_resolve_kernel afterwards; a lane whose queue is full decides on the spot
@@ -446,10 +447,20 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         if (u == 0 && pfetch && w < W && t + 1 < len)   // parents of the next block -> its LDS buffer (read after the next barrier)
             lds[(int)((t + 1) % 3) * 128 + pslot] = __int_as_float(pnext);
         if (prev_active) {
-            const bool trouble = MODE == 0 ? (cntm - cntd != expdiff) : (cntm != before);
-            if (__builtin_amdgcn_ballot_w64(trouble)) {
+            // Pass 1 notes which streamed blocks held any candidate pair at all for this row block: pass 2 tests the
+            // same accumulator values against the same threshold, so it can leave every other block out
+            // (cl_relist_kernel).  Several waves may write the same byte; they all write 1.  An undecided pair is
+            // a candidate pair, so the common case of a unit without any costs one vote.
+            if (MODE == 0) {
+                if (__builtin_amdgcn_ballot_w64(cntm != before)) {
+                    if (lane == 0) A.hit[(long)blockIdx.x * A.nb128 + (col0_prev >> 7)] = 1;
+                    if (__builtin_amdgcn_ballot_w64(cntm - cntd != expdiff)) {
+                        slow_unit(accp, par_prev, u_prev, col0_prev);
+                        expdiff = cntm - cntd;
+                    }
+                }
+            } else if (__builtin_amdgcn_ballot_w64(cntm != before)) {
                 slow_unit(accp, par_prev, u_prev, col0_prev);
-                expdiff = cntm - cntd;
             }
         }
         prev_active = active;
@@ -557,6 +568,41 @@ __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict_
     if (t == 0) act_cnt[ib] = base;
 }
 
+// Between the passes: a row block's list keeps the blocks in which pass 1 saw a candidate pair and that hold a
+// core point -- the only ones in which pass 2 can find an edge.  In place: an entry moves to a position at or
+// before its own, and a chunk of 256 entries is read (barriers of the scan) before any of it is written.
+__global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__restrict__ hit, const int *__restrict__ blk_has_core,
+                                                        int nb, int *__restrict__ act_cnt, int *__restrict__ act_list) {
+    __shared__ int scan[256];
+    __shared__ int base;
+    const int ib = blockIdx.x, t = threadIdx.x;
+    const int total = act_cnt[ib];
+    int *list = act_list + (long)ib * nb;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < total; e0 += 256) {
+        const int e = e0 + t;
+        int jb = 0, keep = 0;
+        if (e < total) {
+            jb = list[e];
+            keep = hit[(long)ib * nb + jb] != 0 && blk_has_core[jb] != 0;
+        }
+        scan[t] = keep;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
+            const int v = t >= o ? scan[t - o] : 0;
+            __syncthreads();
+            scan[t] += v;
+            __syncthreads();
+        }
+        if (keep) list[base + scan[t] - 1] = jb;
+        __syncthreads();
+        if (t == 255) base += scan[255];
+        __syncthreads();
+    }
+    if (t == 0) act_cnt[ib] = base;
+}
+
 // ------------------------------------------------------------------ deferred exact tests of pass 1
 // One thread per queue slot ([wave][slot][lane]).  The pair passes run their 8 waves in lockstep (a
 // barrier per streamed block), so a wave that stops for a float64 test -- two dependent memory round
@@ -656,6 +702,7 @@ struct ClWs {
     unsigned long long *stats;
     float *centre, *radius;
     int *act_cnt, *act_list;
+    unsigned char *hit;
     int *defer_q, *defer_cnt;
     long defer_waves;
 };
@@ -695,7 +742,8 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         w.centre = (float *)take(sizeof(float) * nb * G * 8);
         w.radius = (float *)take(sizeof(float) * nb);
         w.act_cnt = (int *)take(sizeof(int) * nb);
-        w.act_list = (int *)take(sizeof(int) * nb * nb);
+        w.act_list = (int *)take(sizeof(int) * (nb / 2 + 1) * nb);   // one row per workgroup of 256 points
+        w.hit = (unsigned char *)take((nb / 2 + 1) * nb);
     }
     w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
     w.defer_waves = (Npad / CL_ROWBLK) * cl_nsplit(Npad, G) * CL_NW;
@@ -785,6 +833,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     P2N_CHECK_HIP(hipMemsetAsync(w.defer_cnt, 0, sizeof(int) * (size_t)w.defer_waves * 64, stream));   // workgroups without work write nothing
     P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.blk_has_core, 0, sizeof(int) * (Npad / 128 + 1), stream));
+    P2N_CHECK_HIP(hipMemsetAsync(w.hit, 0, (size_t)(nb128 / 2) * nb128, stream));
     p2n_prof_end(ps, stream);
 
     ClArgs a;
@@ -799,7 +848,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const long nrowblk = Npad / CL_ROWBLK;
     a.nsplit = cl_nsplit(Npad, G);
     a.defer_q = w.defer_q; a.defer_cnt = w.defer_cnt; a.defer_cap = CL_DEFER_CAP;
-    a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128;
+    a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128; a.hit = w.hit;
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
     if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, nrowblk, stream);
@@ -819,6 +868,8 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                        w.nrm_core, w.parent, w.nbr_cnt, w.blk_has_core);
     a.nrm_col = w.nrm_core;
     ps = p2n_prof_begin(P2N_K_CLUSTER_LINK, stream);
+    hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, nb128, w.act_cnt,
+                       w.act_list);
     if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, nrowblk, stream);
     else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, nrowblk, stream);
     else rc = cl_launch_pairs<32, 1>(1, a, nrowblk, stream);
