@@ -22,6 +22,7 @@
 // 128/64/32 columns for D <= 64/128/256) per step, double buffered.  D[row][col]: lane = column,
 // register 4g'+j' of lane half h = row 8g'+4h+j'.
 #include <type_traits>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "p2n_common.h"
 
 // The Gram products run on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate) with every
@@ -78,7 +79,8 @@ __device__ __forceinline__ float cl_np_sumsq(const float *e, int n) {
 // thread per point.  out_rm (N,D) row-major and/or the fragment image Xp + fp32 squared norms.
 __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restrict__ emb, long N, long Npad, int D, int G,
                                                            float *__restrict__ out_rm, float *__restrict__ Xp,
-                                                           float *__restrict__ nrm, float *__restrict__ Xb) {
+                                                           float *__restrict__ nrm, float *__restrict__ Xb,
+                                                           const int *__restrict__ perm) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= Npad) return;
     if (i >= N) {   // pad rows: zero vectors that are never anybody's neighbour
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
         }
         return;
     }
-    const float *e = emb + i * D;
+    const float *e = emb + (perm ? (long)perm[i] : i) * D;   // row i of the working order
     const float ss = cl_np_sumsq<2>(e, D);
     // sqrt and divide through double: correctly rounded in fp32 (53 >= 2*24+2) whatever the fp32 fast paths do
     const float den = __fadd_rn((float)sqrt((double)ss), 1e-8f);
@@ -122,6 +124,35 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
         }
     }
     if (Xp) nrm[i] = (float)(-0.5 * sq);   // nh = -|x|^2/2, the accumulator start value of the pair passes
+}
+
+// ------------------------------------------------------------------ working order
+// The pair passes prune by blocks of 128 consecutive rows, which only pays when rows that are close in the
+// embedding are close in the index.  A scan may come in any order, so the rows are worked on in the order of a
+// 32-bit code -- the signs of 32 fixed +-1 projections, one bit each: rows of one instance share most bits and
+// land in a few runs.  The order changes nothing in the result (neighbourhood sizes, the sets and the border rule
+// are properties of the point set; cluster numbers are re-derived from the caller's indices, cl_rank_kernel),
+// only which blocks ever meet.
+__global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ emb, long N, int D, unsigned *__restrict__ keys,
+                                                      int *__restrict__ vals) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float *e = emb + i * D;
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+    for (int d = 0; d < D; ++d) {
+        unsigned hsh = (unsigned)d * 0x9E3779B1u + 0x7F4A7C15u;   // the 32 signs of dimension d
+        hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
+        const float x = e[d];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc[k] += __uint_as_float(__float_as_uint(x) ^ ((hsh >> k & 1u) << 31));
+    }
+    unsigned key = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) key |= (unsigned)(acc[k] > 0.f) << k;
+    keys[i] = key;
+    vals[i] = (int)i;
 }
 
 // ------------------------------------------------------------------ exact pair test
@@ -195,6 +226,7 @@ struct ClArgs {
     const int *act_cnt;     // per 256-point row block (one workgroup): number of active 128-point blocks
     const int *act_list;    // [row block][nb128]: their indices, ascending
     int nb128;
+    int list_cap;           // pass 2: at most this many entries of a row block's list (the seeding launch), 0 = all
     unsigned char *hit;     // pass 1 writes [row block][nb128]: 1 where some pair of the two blocks came within the "maybe" threshold
     unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
     // pass 1: undecided pairs are queued per lane ([wave][slot][lane] = partner index) and decided by
@@ -216,7 +248,8 @@ struct ClArgs {
 #define CL_BLK_FLOATS (8192 + 128)   // 32 fragments + nh[128] per LDS buffer
 #define CL_RING 3                          // streamed blocks resident in LDS: one in use, two in flight
 #define CL_PAR_BASE (CL_RING * CL_BLK_FLOATS)   // then three rotating parent[128] slots (pass 2)
-#define CL_LDS_FLOATS (CL_PAR_BASE + 3 * 128)
+#define CL_PU_BASE (CL_PAR_BASE + 3 * 128)       // then per parent slot: the common parent of each fetching wave's columns
+#define CL_LDS_FLOATS (CL_PU_BASE + 8)
 #define CL_SLIST_MAX 2048   // active-list entries one workgroup may hold in LDS (after the ring)
 
 #define CL_NW 8   // waves per workgroup, one workgroup per CU: 256 wave-owned points share one streamed block
@@ -239,12 +272,14 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     // The streamed blocks of this row block come from its active list: 128-point blocks whose bounding
     // sphere can reach ours within eps (cl_active_kernel); everything else is skipped without a load.
     constexpr int SUB = 128 / JB;         // streamed blocks per 128-point block
-    const int total = A.act_cnt[blockIdx.x];
+    int total = A.act_cnt[blockIdx.x];
+    if (MODE == 1 && A.list_cap > 0 && total > A.list_cap) total = A.list_cap;
     const int e0 = (int)((long)total * blockIdx.y / A.nsplit), e1 = (int)((long)total * (blockIdx.y + 1) / A.nsplit);
     const long len = (long)(e1 - e0) * SUB;
     if (len <= 0) return;
     int *slist = reinterpret_cast<int *>(lds + CL_LDS_FLOATS);   // this workgroup's slice of the list
     for (int i = threadIdx.x; i < e1 - e0; i += CL_NW * 64) slist[i] = A.act_list[(long)blockIdx.x * A.nb128 + e0 + i];
+    if (MODE == 1 && threadIdx.x < 8) lds[CL_PU_BASE + threadIdx.x] = __int_as_float(-1);   // pass 2, a wave that stages no parents: "no core point"
     __syncthreads();
     auto jbof = [&](long pos) -> long { return (long)slist[pos / SUB] * SUB + pos % SUB; };
     // Pass 1: every workgroup walks the blocks in the same order (a block is fetched from HBM once per
@@ -272,6 +307,15 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     // the block's last unit), so three slots keep writer and readers apart.
     const bool pfetch = MODE == 1 && wave >= 2 && (wave - 2) * 64 < JB;
     const int pslot = CL_PAR_BASE + (wave - 2) * 64 + lane;
+    // What the columns one fetching wave staged have in common: -1 none of them is a core point (non-core points carry
+    // parent -1), p >= 0 every core point among them names p, -2 they name different parents.
+    auto common_parent = [&](int pv) -> int {
+        const bool in = (wave - 2) * 64 + lane < JB && pv != -1;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+        if (!m) return -1;
+        const int first = __builtin_amdgcn_readlane(pv, __builtin_ctzll(m));
+        return __builtin_amdgcn_ballot_w64(in && pv != first) ? -2 : first;
+    };
     // block numbers are looked up one step ahead of their use: the LDS read is off the critical path
     long jb_now = jbof(cur);
     long jb_nxt = jbof(cur + 1 == len ? 0 : cur + 1);
@@ -279,7 +323,12 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     if (len > 1) stage(jb_nxt, 1);
     // LDS-DMA instructions one stage() issues from this wave: what may stay in flight at a block entry
     const bool dma5 = wave * 64 < JB;
-    if (pfetch) lds[pslot] = __int_as_float(CL_LD(A.parent + jb_now * JB + (wave - 2) * 64 + lane));
+    if (pfetch) {
+        const int pv = CL_LD(A.parent + jb_now * JB + (wave - 2) * 64 + lane);
+        lds[pslot] = __int_as_float(pv);
+        const int cp = common_parent(pv);
+        if (lane == 0) lds[CL_PU_BASE + wave - 2] = __int_as_float(cp);
+    }
     int pnext = 0;
     int pi_nxt = MODE == 1 ? CL_LD(A.parent + (((long)blockIdx.x * CL_NW + wave) * 32 + (lane & 31))) : 0;
 
@@ -360,6 +409,9 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                     cntd += cl_exact_within(A.Xp, G, my, other, A.eps2);
                 }
             } else {
+                // the staged parent against the CURRENT own parent: after a call the row usually names the root that
+                // the rest of the block's columns name too, and those edges need no call of their own
+                if (mycore && __float_as_int(par[(u * UT + ut) * 32 + 8 * (r >> 2) + 4 * h + (r & 3)]) == pi) continue;
                 bool ok = sure >> e & 1;
                 if (!ok) {
                     ok = cl_exact_within(A.Xp, G, my, other, A.eps2);
@@ -369,7 +421,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                     if (mycore) {
                         pi = cl_unite(A.parent, (int)my, (int)other);
                         atomicAdd(A.stats + 2, 1ull);
-                    } else {
+                    } else if (A.list_cap == 0) {   // (the seeding launch leaves the border lists to the full pass: no duplicates)
                         atomicAdd(A.stats + 3, 1ull);
                         const int slot = atomicAdd(A.nbr_cnt + my, 1);
                         if (slot < A.cap) A.nbr[my * A.cap + slot] = (int)other;
@@ -418,6 +470,15 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                 jb_now = jb_nxt;
                 jb_nxt = jb_after;
                 blk_active = MODE == 0 || A.colblk_has_core[(jb_cur * JB) >> 7] != 0;
+                if (MODE == 1) {
+                    // A cell whose columns all name one parent that every row of this wave names too joins nothing
+                    // (both values are past ancestors, and sets only grow): the wave sits the block out.  Rows that
+                    // are not core points still need their neighbour lists, so a wave that holds one never skips.
+                    const int c0 = __float_as_int(lds[CL_PU_BASE + (int)(t % 3) * 2]), c1 = __float_as_int(lds[CL_PU_BASE + (int)(t % 3) * 2 + 1]);
+                    const int cp = (c0 == -2 || c1 == -2 || (c0 >= 0 && c1 >= 0 && c0 != c1)) ? -2 : (c0 > c1 ? c0 : c1);
+                    const bool settled = hh == __builtin_inff() || (mycore && pi == cp);
+                    if (cp == -1 || (cp >= 0 && !__builtin_amdgcn_ballot_w64(!settled))) blk_active = false;
+                }
             }
             active = blk_active;
         }
@@ -445,7 +506,11 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             }
         }
         if (u == 0 && pfetch && w < W && t + 1 < len)   // parents of the next block -> its LDS buffer (read after the next barrier)
+        {
             lds[(int)((t + 1) % 3) * 128 + pslot] = __int_as_float(pnext);
+            const int cp = common_parent(pnext);
+            if (lane == 0) lds[CL_PU_BASE + (int)((t + 1) % 3) * 2 + wave - 2] = __int_as_float(cp);
+        }
         if (prev_active) {
             // Pass 1 notes which streamed blocks held any candidate pair at all for this row block: pass 2 tests the
             // same accumulator values against the same threshold, so it can leave every other block out
@@ -500,7 +565,11 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
     const float cntf = red[0];
     __syncthreads();
-    if (cntf == 0.f) { if (t == 0) radius[b] = -1.f; if (t < 8 * G) centre[(long)b * 8 * G + t] = 0.f; return; }
+    if (cntf == 0.f) {
+        if (t == 0) radius[b] = -1.f;
+        for (int k = t; k < 8 * G; k += 128) centre[(long)b * 8 * G + k] = 0.f;
+        return;
+    }
     for (int k = 0; k < 8 * G; ++k) {   // column means (D <= 256: at most 256 short reductions)
         const float v = real ? px[(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (k & 3)] : 0.f;
         red[t] = v;
@@ -519,7 +588,7 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     __syncthreads();
     for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
     if (t == 0) radius[b] = sqrtf(red[0]) + CL_SPH_MARGIN;
-    if (t < 8 * G) centre[(long)b * 8 * G + t] = cen[t];
+    for (int k = t; k < 8 * G; k += 128) centre[(long)b * 8 * G + k] = cen[k];   // (up to 256 dimensions, 128 threads)
 }
 
 // grid = row groups of 256 points.  list[ib][0..cnt) = column blocks jb (ascending) that can reach either of the
@@ -636,14 +705,25 @@ __global__ __launch_bounds__(256) void cl_prepare_link_kernel(const int *__restr
     const bool k = i < N && cnt[i] >= min_samples;
     core[i] = k;
     nrm_core[i] = k ? nrm[i] : -__builtin_inff();
-    parent[i] = (int)i;
+    parent[i] = k ? (int)i : -1;   // -1: not a core point (never a member of a set; the link pass reads it as "no parent")
     nbr_cnt[i] = 0;
     if (k) blk_has_core[i >> 7] = 1;   // benign race: everybody writes 1
 }
 
+// between the seeding launch and the full link pass: every core point names its root
+__global__ __launch_bounds__(256) void cl_flatten_kernel(int *__restrict__ parent, const unsigned char *__restrict__ core, long N) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N || !core[i]) return;
+    const int r = cl_find(parent, (int)i);
+    if (r != (int)i) CL_ST(parent + i, r);   // a non-root's parent: only ever shortened
+}
+
 // roots -> consecutive cluster numbers 1.. in ascending root order (single workgroup scan)
+// With a working order (owner != null) the scan runs over the CALLER's indices: owner[o] = root of the set whose
+// lowest caller index among core points is o (-1 elsewhere), so sets are numbered as if the rows had never moved.
 __global__ __launch_bounds__(1024) void cl_rank_kernel(int *__restrict__ parent, const unsigned char *__restrict__ core, long N,
-                                                       int *__restrict__ rank, int *__restrict__ num_clusters) {
+                                                       int *__restrict__ rank, int *__restrict__ num_clusters,
+                                                       const int *__restrict__ owner) {
     __shared__ int wsum[16];
     __shared__ int base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -651,8 +731,13 @@ __global__ __launch_bounds__(1024) void cl_rank_kernel(int *__restrict__ parent,
     __syncthreads();
     for (long s = 0; s < N; s += 1024) {
         const long i = s + threadIdx.x;
-        int root = 0;
-        if (i < N && core[i]) {
+        int root = 0, slot = (int)i;
+        if (owner) {
+            if (i < N) {
+                slot = owner[i];
+                root = slot >= 0;
+            }
+        } else if (i < N && core[i]) {
             const int r = cl_find(parent, (int)i);
             parent[i] = r;                       // flattened: every core point names its root
             root = (r == (int)i);
@@ -663,7 +748,7 @@ __global__ __launch_bounds__(1024) void cl_rank_kernel(int *__restrict__ parent,
         __syncthreads();
         int off = base;
         for (int w = 0; w < wave; ++w) off += wsum[w];
-        if (root) rank[i] = off + before + 1;
+        if (root) rank[slot] = off + before + 1;
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0;
@@ -677,21 +762,41 @@ __global__ __launch_bounds__(1024) void cl_rank_kernel(int *__restrict__ parent,
 
 __global__ __launch_bounds__(256) void cl_label_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
                                                        const int *__restrict__ rank, const int *__restrict__ nbr_cnt,
-                                                       const int *__restrict__ nbr, int cap, long N, int32_t *__restrict__ labels) {
+                                                       const int *__restrict__ nbr, int cap, long N, int32_t *__restrict__ labels,
+                                                       const int *__restrict__ perm) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    const long o = perm ? (long)perm[i] : i;   // the caller's index of working row i
     if (core[i]) {
-        labels[i] = rank[parent[i]];
+        labels[o] = rank[parent[i]];
         return;
     }
     int n = nbr_cnt[i];
     n = n < cap ? n : cap;
-    int best = 0x7fffffff;   // lowest root = lowest-numbered cluster among the core neighbours
+    int best = 0x7fffffff;   // the lowest-numbered cluster among the core neighbours
     for (int q = 0; q < n; ++q) {
-        const int r = parent[nbr[i * cap + q]];
+        const int r = rank[parent[nbr[i * cap + q]]];
         best = r < best ? r : best;
     }
-    labels[i] = n > 0 ? rank[best] : 0;
+    labels[o] = n > 0 ? best : 0;
+}
+
+// working order only: the lowest caller index among the core points of every set, then the set's root filed under it
+__global__ __launch_bounds__(256) void cl_minorig_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
+                                                         const int *__restrict__ perm, long N, int *__restrict__ minorig) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < N && core[i]) atomicMin(minorig + parent[i], perm[i]);
+}
+__global__ __launch_bounds__(256) void cl_owner_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core, long N,
+                                                       const int *__restrict__ minorig, int *__restrict__ owner) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < N && core[i] && parent[i] == (int)i) owner[minorig[i]] = (int)i;
+}
+__global__ __launch_bounds__(256) void cl_unpermute_kernel(const int *__restrict__ src, const int *__restrict__ perm,
+                                                           const unsigned long long *__restrict__ sorted_flag, long N,
+                                                           int32_t *__restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) dst[*sorted_flag ? (long)perm[i] : i] = src[i];
 }
 
 // ------------------------------------------------------------------ host side
@@ -703,6 +808,11 @@ struct ClWs {
     float *centre, *radius;
     int *act_cnt, *act_list;
     unsigned char *hit;
+    unsigned *key_a, *key_b;   // working order: code of every row, double-buffered for the sort
+    int *perm, *val_b;         // working row -> caller's index (the sort's values)
+    int *minorig, *owner;
+    void *sort_tmp;
+    size_t sort_tmp_bytes;
     int *defer_q, *defer_cnt;
     long defer_waves;
 };
@@ -746,6 +856,14 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         w.hit = (unsigned char *)take((nb / 2 + 1) * nb);
     }
     w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
+    w.key_a = (unsigned *)take(sizeof(int) * Npad);
+    w.key_b = (unsigned *)take(sizeof(int) * Npad);
+    w.perm = (int *)take(sizeof(int) * Npad);
+    w.val_b = (int *)take(sizeof(int) * Npad);
+    w.minorig = (int *)take(sizeof(int) * Npad);
+    w.owner = (int *)take(sizeof(int) * Npad);
+    w.sort_tmp_bytes = (size_t)Npad * 8 + (4u << 20);   // the double-buffered radix sort needs its digit counts only; checked at the call
+    w.sort_tmp = take(w.sort_tmp_bytes);
     w.defer_waves = (Npad / CL_ROWBLK) * cl_nsplit(Npad, G) * CL_NW;
     w.defer_q = (int *)take(sizeof(int) * (size_t)w.defer_waves * CL_DEFER_CAP * 64);
     w.defer_cnt = (int *)take(sizeof(int) * (size_t)w.defer_waves * 64);
@@ -781,9 +899,20 @@ extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, v
     P2N_REQUIRE(emb && out, "p2n_normalize_rows: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(cl_normalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, N, D, (D + 7) / 8,
-                       out, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+                       out, (float *)nullptr, (float *)nullptr, (float *)nullptr, (const int *)nullptr);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
+}
+
+// rows are worked on in code order unless P2N_CL_SORT=0 (read per call: tests cover both orders); tiny inputs are one block anyway
+static bool p2n_cluster_sorts(long N) {
+    const char *e = getenv("P2N_CL_SORT");
+    return N > 256 && !(e && atoi(e) == 0);
+}
+
+static int p2n_cluster_seed_blocks() {
+    static const int v = [] { const char *e = getenv("P2N_CL_SEED"); return e ? atoi(e) : 1; }();
+    return v;
 }
 
 template <int G, int CT>
@@ -823,7 +952,23 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     }
     const unsigned nb256 = (unsigned)((Npad + 255) / 256);
     int ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
-    hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm, w.Xb);
+    P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
+    const int *perm = nullptr;
+    if (p2n_cluster_sorts(N)) {   // the working order (cl_code_kernel)
+        hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, D, w.key_a, w.perm);
+        rocprim::double_buffer<unsigned> kb(w.key_a, w.key_b);
+        rocprim::double_buffer<int> vb(w.perm, w.val_b);
+        size_t tmp = 0;
+        P2N_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kb, vb, (size_t)N, 0, 32, stream));
+        P2N_REQUIRE(tmp <= w.sort_tmp_bytes, "p2n_cluster_embeddings: sort scratch %zu > %zu bytes", tmp, w.sort_tmp_bytes);
+        P2N_CHECK_HIP(rocprim::radix_sort_pairs(w.sort_tmp, tmp, kb, vb, (size_t)N, 0, 32, stream));
+        if (vb.current() != w.perm)
+            P2N_CHECK_HIP(hipMemcpyAsync(w.perm, vb.current(), sizeof(int) * N, hipMemcpyDeviceToDevice, stream));
+        P2N_CHECK_HIP(hipMemsetAsync(w.stats + 7, 1, 1, stream));   // stats[7] = 1: this workspace holds a working order
+        perm = w.perm;
+    }
+    hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm, w.Xb,
+                       perm);
     const int nb128 = (int)(Npad / 128);
     hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (8 * G + 128), stream, w.Xp, w.nrm, G, w.centre,
                        w.radius);
@@ -831,7 +976,6 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                        8 * G, (float)eps, w.act_cnt, w.act_list);
     P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.defer_cnt, 0, sizeof(int) * (size_t)w.defer_waves * 64, stream));   // workgroups without work write nothing
-    P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.blk_has_core, 0, sizeof(int) * (Npad / 128 + 1), stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.hit, 0, (size_t)(nb128 / 2) * nb128, stream));
     p2n_prof_end(ps, stream);
@@ -848,7 +992,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const long nrowblk = Npad / CL_ROWBLK;
     a.nsplit = cl_nsplit(Npad, G);
     a.defer_q = w.defer_q; a.defer_cnt = w.defer_cnt; a.defer_cap = CL_DEFER_CAP;
-    a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128; a.hit = w.hit;
+    a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128; a.hit = w.hit; a.list_cap = 0;
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
     if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, nrowblk, stream);
@@ -870,6 +1014,21 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     ps = p2n_prof_begin(P2N_K_CLUSTER_LINK, stream);
     hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, nb128, w.act_cnt,
                        w.act_list);
+    // Seeding launch: every row block meets only the first few blocks of its list.  Lists ascend, so the row blocks
+    // of one instance all meet the instance's lowest blocks and hang themselves under the same roots; after the
+    // flattening the full pass below finds staged parent == own parent for nearly every edge and streams through
+    // (it still sees every edge: the seeding only saves it the calls).
+    const int seed = p2n_cluster_seed_blocks();
+    if (seed > 0) {
+        ClArgs s2 = a;
+        s2.list_cap = seed;
+        s2.nsplit = 1;
+        if (G == 8) rc = cl_launch_pairs<8, 4>(1, s2, nrowblk, stream);
+        else if (G == 16) rc = cl_launch_pairs<16, 2>(1, s2, nrowblk, stream);
+        else rc = cl_launch_pairs<32, 1>(1, s2, nrowblk, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cl_flatten_kernel, dim3(nb256), dim3(256), 0, stream, w.parent, w.core, N);
+    }
     if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, nrowblk, stream);
     else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, nrowblk, stream);
     else rc = cl_launch_pairs<32, 1>(1, a, nrowblk, stream);
@@ -877,9 +1036,18 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     if (rc) return rc;
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
-    hipLaunchKernelGGL(cl_rank_kernel, dim3(1), dim3(1024), 0, stream, w.parent, w.core, N, w.rank, num_clusters);
+    if (perm) {   // number the sets by the caller's indices
+        const unsigned nbn = (unsigned)((N + 255) / 256);
+        hipLaunchKernelGGL(cl_flatten_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, N);
+        P2N_CHECK_HIP(hipMemsetAsync(w.minorig, 0x7f, sizeof(int) * N, stream));
+        P2N_CHECK_HIP(hipMemsetAsync(w.owner, 0xff, sizeof(int) * N, stream));
+        hipLaunchKernelGGL(cl_minorig_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, perm, N, w.minorig);
+        hipLaunchKernelGGL(cl_owner_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, N, w.minorig, w.owner);
+    }
+    hipLaunchKernelGGL(cl_rank_kernel, dim3(1), dim3(1024), 0, stream, w.parent, w.core, N, w.rank, num_clusters,
+                       perm ? w.owner : (const int *)nullptr);
     hipLaunchKernelGGL(cl_label_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.parent, w.core, w.rank,
-                       w.nbr_cnt, w.nbr, cap, N, labels);
+                       w.nbr_cnt, w.nbr, cap, N, labels, perm);
     p2n_prof_end(ps, stream);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
@@ -893,7 +1061,9 @@ extern "C" int p2n_cluster_counts(const void *workspace, long N, int D, int min_
     cl_geometry(D, G, CT);
     ClWs w;
     cl_carve(w, (char *)workspace, (N + CL_NPAD_UNIT - 1) / CL_NPAD_UNIT * CL_NPAD_UNIT, G, N, min_samples - 1);
-    P2N_CHECK_HIP(hipMemcpyAsync(counts, w.cnt, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    hipLaunchKernelGGL(cl_unpermute_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w.cnt, w.perm,
+                       w.stats + 7, N, counts);
+    P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
 
