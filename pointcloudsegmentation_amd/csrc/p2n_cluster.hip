@@ -552,7 +552,8 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
 // scene are farther apart than eps and never need their 128 x 128 distance tile.
 #define CL_SPH_MARGIN 1e-4f   // fp32 slack of centre / radius / centre-distance arithmetic (vectors are unit length)
 __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
-                                                        float *__restrict__ centre, float *__restrict__ radius) {
+                                                        float *__restrict__ centre, float *__restrict__ radius,
+                                                        float *__restrict__ csq) {
     extern __shared__ float sph[];   // [8G] centre, then reduction scratch
     float *cen = sph, *red = sph + 8 * G;
     const int b = blockIdx.x, t = threadIdx.x;
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     const float cntf = red[0];
     __syncthreads();
     if (cntf == 0.f) {
-        if (t == 0) radius[b] = -1.f;
+        if (t == 0) { radius[b] = -1.f; csq[b] = 0.f; }
         for (int k = t; k < 8 * G; k += 128) centre[(long)b * 8 * G + k] = 0.f;
         return;
     }
@@ -587,7 +588,12 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     red[t] = d2;
     __syncthreads();
     for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
-    if (t == 0) radius[b] = sqrtf(red[0]) + CL_SPH_MARGIN;
+    if (t == 0) {
+        radius[b] = sqrtf(red[0]) + CL_SPH_MARGIN;
+        float sq = 0.f;   // |centre|^2 for cl_reach_kernel
+        for (int k = 0; k < 8 * G; ++k) sq = fmaf(cen[k], cen[k], sq);
+        csq[b] = sq;
+    }
     for (int k = t; k < 8 * G; k += 128) centre[(long)b * 8 * G + k] = cen[k];   // (up to 256 dimensions, 128 threads)
 }
 
@@ -637,11 +643,107 @@ __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict_
     if (t == 0) act_cnt[ib] = base;
 }
 
+// The bounding spheres alone prune poorly once a block holds an outlier: its sphere spans everything.  A pair
+// (i in A, j in B) within eps needs i within eps of B's sphere AND j within eps of A's sphere, so per listed pair
+// of blocks this kernel notes whether ANY point of A reaches B's sphere; cl_relist_kernel keeps a block only if
+// the note holds both ways round.  An outlier block against a tight instance block fails the second half: none
+// of the outliers is near the instance.  One workgroup per block A (thread = point), the listed centres staged
+// through LDS eight at a time; fp32 dot products with CL_REACH_SLACK on the squared distance.
+#define CL_REACH_TB 16
+#define CL_REACH_SLACK 4e-5f   // > 256 * 2^-24 * 2 (fp32 dot of unit-length vectors, twice in d^2) + the roundings of the three terms
+template <int NCH>
+__global__ __launch_bounds__(128) void cl_reach_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
+                                                       const float *__restrict__ centre, const float *__restrict__ radius,
+                                                       const float *__restrict__ csq, int nb, float eps,
+                                                       const int *__restrict__ act_cnt, const int *__restrict__ act_list,
+                                                       unsigned char *__restrict__ reach) {
+    // two tiles of centres in LDS: the next one is staged while this one is used, one barrier per tile
+    __shared__ __attribute__((aligned(16))) float cs[2][CL_REACH_TB][NCH * 64];
+    __shared__ float c2[2][CL_REACH_TB], lim[2][CL_REACH_TB];
+    __shared__ int blk[2][CL_REACH_TB], any[2][2][CL_REACH_TB];
+    const int A = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long i = (long)A * 128 + t;
+    const float nhi = nh[i];
+    const bool real = nhi > -__builtin_inff();
+    const float x2 = real ? -2.f * nhi : 0.f;
+    const float *px = Xp + ((i >> 5) * (8 * NCH) * 64 + (i & 31)) * 4;
+    const int wg = A >> 1, total = act_cnt[wg];
+    const int *list = act_list + (long)wg * nb;
+    constexpr int Dp = 64 * NCH;   // the padded dimension: G = 8 NCH fragments (cl_geometry)
+    f32x4 x[16];
+    auto load_x = [&](int ch) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {   // dims 64 ch + 4 q ..: fragment g = 8 ch + q / 2, half q % 2
+            const int g = 8 * ch + (q >> 1);
+            x[q] = *reinterpret_cast<const f32x4 *>(px + g * 256 + (q & 1) * 128);
+        }
+    };
+    auto stage = [&](int e0, int buf) {
+        for (int q = t; q < CL_REACH_TB * NCH * 16; q += 128) {   // float4 pieces
+            const int b = q / (NCH * 16), k4 = q % (NCH * 16);
+            const int B = e0 + b < total ? list[e0 + b] : -1;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (B >= 0) v = *reinterpret_cast<const f32x4 *>(centre + (long)B * Dp + 4 * k4);
+            *reinterpret_cast<f32x4 *>(&cs[buf][b][4 * k4]) = v;
+        }
+        if (t < CL_REACH_TB) {
+            const int B = e0 + t < total ? list[e0 + t] : -1;
+            blk[buf][t] = B;
+            const float r = B >= 0 ? radius[B] : -1.f;
+            const float R = r + eps + CL_SPH_MARGIN;
+            lim[buf][t] = r >= 0.f ? R * R + CL_REACH_SLACK : -1.f;
+            c2[buf][t] = B >= 0 ? csq[B] : 0.f;
+        }
+    };
+    if (NCH == 1) load_x(0);
+    if (total > 0) stage(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int e0 = 0; e0 < total; e0 += CL_REACH_TB, buf ^= 1) {
+        if (e0 + CL_REACH_TB < total) stage(e0 + CL_REACH_TB, buf ^ 1);
+        float acc[CL_REACH_TB];
+#pragma unroll
+        for (int b = 0; b < CL_REACH_TB; ++b) acc[b] = 0.f;
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (NCH > 1) load_x(ch);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+#pragma unroll
+                for (int b = 0; b < CL_REACH_TB; ++b) {
+                    const f32x4 c = *reinterpret_cast<const f32x4 *>(&cs[buf][b][ch * 64 + 4 * q]);
+                    acc[b] = fmaf(x[q][0], c[0], acc[b]);
+                    acc[b] = fmaf(x[q][1], c[1], acc[b]);
+                    acc[b] = fmaf(x[q][2], c[2], acc[b]);
+                    acc[b] = fmaf(x[q][3], c[3], acc[b]);
+                }
+                // one q at a time: left alone the compiler orders the multiply-adds centre by centre, which needs all
+                // 256 staged vectors of a tile in registers at once (hundreds of spills)
+#pragma unroll
+                for (int b = 0; b < CL_REACH_TB; ++b) asm volatile("" : "+v"(acc[b]));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < CL_REACH_TB; ++b) {
+            const float d2 = x2 - 2.f * acc[b] + c2[buf][b];
+            // (no test of lim's sign: a branch on it would pull this centre's whole dot product behind it, and with
+            // it every staged value into registers; an empty block's limit of -1 lies below any d2)
+            const bool ok = real & (d2 <= lim[buf][b]);
+            const bool hit = __builtin_amdgcn_ballot_w64(ok) != 0;
+            if (lane == 0) any[buf][wave][b] = hit;
+        }
+        __syncthreads();   // the votes of both waves; the next tile is staged; everybody has left the tile before this one
+        if (t < CL_REACH_TB && blk[buf][t] >= 0) reach[(long)A * nb + blk[buf][t]] = (unsigned char)(any[buf][0][t] | any[buf][1][t]);
+    }
+}
+
 // Between the passes: a row block's list keeps the blocks in which pass 1 saw a candidate pair and that hold a
 // core point -- the only ones in which pass 2 can find an edge.  In place: an entry moves to a position at or
 // before its own, and a chunk of 256 entries is read (barriers of the scan) before any of it is written.
+// With `reach` (before pass 1) the rule is the point-to-sphere test of cl_reach_kernel instead, both ways round.
 __global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__restrict__ hit, const int *__restrict__ blk_has_core,
-                                                        int nb, int *__restrict__ act_cnt, int *__restrict__ act_list) {
+                                                        const unsigned char *__restrict__ reach, int nb,
+                                                        int *__restrict__ act_cnt, int *__restrict__ act_list) {
     __shared__ int scan[256];
     __shared__ int base;
     const int ib = blockIdx.x, t = threadIdx.x;
@@ -654,7 +756,12 @@ __global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__r
         int jb = 0, keep = 0;
         if (e < total) {
             jb = list[e];
-            keep = hit[(long)ib * nb + jb] != 0 && blk_has_core[jb] != 0;
+            if (reach) {
+                const long a0 = 2L * ib, a1 = a0 + 1;
+                keep = (reach[a0 * nb + jb] && reach[(long)jb * nb + a0]) || (reach[a1 * nb + jb] && reach[(long)jb * nb + a1]);
+            } else {
+                keep = hit[(long)ib * nb + jb] != 0 && blk_has_core[jb] != 0;
+            }
         }
         scan[t] = keep;
         __syncthreads();
@@ -805,9 +912,9 @@ struct ClWs {
     int *cnt, *parent, *nbr_cnt, *rank, *blk_has_core, *nbr;
     unsigned char *core;
     unsigned long long *stats;
-    float *centre, *radius;
+    float *centre, *radius, *csq;
     int *act_cnt, *act_list;
-    unsigned char *hit;
+    unsigned char *hit, *reach;
     unsigned *key_a, *key_b;   // working order: code of every row, double-buffered for the sort
     int *perm, *val_b;         // working row -> caller's index (the sort's values)
     int *minorig, *owner;
@@ -851,9 +958,11 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         const size_t nb = (size_t)Npad / 128;
         w.centre = (float *)take(sizeof(float) * nb * G * 8);
         w.radius = (float *)take(sizeof(float) * nb);
+        w.csq = (float *)take(sizeof(float) * nb);
         w.act_cnt = (int *)take(sizeof(int) * nb);
         w.act_list = (int *)take(sizeof(int) * (nb / 2 + 1) * nb);   // one row per workgroup of 256 points
         w.hit = (unsigned char *)take((nb / 2 + 1) * nb);
+        w.reach = (unsigned char *)take(nb * nb);   // [block A][block B]: some point of A reaches B's sphere
     }
     w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
     w.key_a = (unsigned *)take(sizeof(int) * Npad);
@@ -908,6 +1017,11 @@ extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, v
 static bool p2n_cluster_sorts(long N) {
     const char *e = getenv("P2N_CL_SORT");
     return N > 256 && !(e && atoi(e) == 0);
+}
+
+static bool p2n_cluster_refines() {
+    const char *e = getenv("P2N_CL_REACH");
+    return !(e && atoi(e) == 0);
 }
 
 static int p2n_cluster_seed_blocks() {
@@ -971,9 +1085,23 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                        perm);
     const int nb128 = (int)(Npad / 128);
     hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (8 * G + 128), stream, w.Xp, w.nrm, G, w.centre,
-                       w.radius);
+                       w.radius, w.csq);
     hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
                        8 * G, (float)eps, w.act_cnt, w.act_list);
+    if (p2n_cluster_refines()) {
+        P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));
+        if (G == 8)
+            hipLaunchKernelGGL(cl_reach_kernel<1>, dim3(nb128), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
+                               w.act_cnt, w.act_list, w.reach);
+        else if (G == 16)
+            hipLaunchKernelGGL(cl_reach_kernel<2>, dim3(nb128), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
+                               w.act_cnt, w.act_list, w.reach);
+        else
+            hipLaunchKernelGGL(cl_reach_kernel<4>, dim3(nb128), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
+                               w.act_cnt, w.act_list, w.reach);
+        hipLaunchKernelGGL(cl_relist_kernel, dim3(nb128 / 2), dim3(256), 0, stream, (const unsigned char *)nullptr, (const int *)nullptr,
+                           w.reach, nb128, w.act_cnt, w.act_list);
+    }
     P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.defer_cnt, 0, sizeof(int) * (size_t)w.defer_waves * 64, stream));   // workgroups without work write nothing
     P2N_CHECK_HIP(hipMemsetAsync(w.blk_has_core, 0, sizeof(int) * (Npad / 128 + 1), stream));
@@ -1012,7 +1140,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                        w.nrm_core, w.parent, w.nbr_cnt, w.blk_has_core);
     a.nrm_col = w.nrm_core;
     ps = p2n_prof_begin(P2N_K_CLUSTER_LINK, stream);
-    hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, nb128, w.act_cnt,
+    hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, (const unsigned char *)nullptr, nb128, w.act_cnt,
                        w.act_list);
     // Seeding launch: every row block meets only the first few blocks of its list.  Lists ascend, so the row blocks
     // of one instance all meet the instance's lowest blocks and hang themselves under the same roots; after the

@@ -11,8 +11,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
     n = r["Kernel_Name"]
-    if not n.startswith("cl_") and "cl_pair" not in n:
+    if "cl_" not in n and "rocprim" not in n:
         continue
+    n = n.replace("void ", "")
     key = (n[:44], r.get("Grid_Size_X"), r.get("Grid_Size_Y"))
     agg.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in agg.items():
