@@ -347,6 +347,9 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     const long dq_wave = ((long)blockIdx.y * gridDim.x + blockIdx.x) * CL_NW + wave;
     int cntd = 0, cntm = 0, expdiff = 0;   // pass 1: definite(+resolved) / maybe counts; pass 2: cntm = maybe-edges seen
     int pi = 0;
+    // pass 2: diagnostics counters, flushed once per wave at the end (an atomic per event on one shared word was a
+    // large part of the slow path's time)
+    unsigned st_exact = 0, st_union = 0, st_border = 0;
 
     // ---- per-unit pieces --------------------------------------------------
     auto init_acc = [&](f32x16(&acc)[UT], const float *blk, int u) __attribute__((always_inline)) {
@@ -415,14 +418,14 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                 bool ok = sure >> e & 1;
                 if (!ok) {
                     ok = cl_exact_within(A.Xp, G, my, other, A.eps2);
-                    atomicAdd(A.stats + 1, 1ull);
+                    ++st_exact;
                 }
                 if (ok) {
                     if (mycore) {
                         pi = cl_unite(A.parent, (int)my, (int)other);
-                        atomicAdd(A.stats + 2, 1ull);
+                        ++st_union;
                     } else if (A.list_cap == 0) {   // (the seeding launch leaves the border lists to the full pass: no duplicates)
-                        atomicAdd(A.stats + 3, 1ull);
+                        ++st_border;
                         const int slot = atomicAdd(A.nbr_cnt + my, 1);
                         if (slot < A.cap) A.nbr[my * A.cap + slot] = (int)other;
                     }
@@ -539,8 +542,27 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         unit_step(accA, accB, w, std::integral_constant<int, 0>{});
         if (w + 1 <= W) unit_step(accB, accA, w + 1, std::integral_constant<int, (UPS > 1 ? 1 : 0)>{});
     }
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            st_exact += __shfl_xor(st_exact, o);
+            st_union += __shfl_xor(st_union, o);
+            st_border += __shfl_xor(st_border, o);
+        }
+        if (lane == 0) {
+            if (st_exact) atomicAdd(A.stats + 1, (unsigned long long)st_exact);
+            if (st_union) atomicAdd(A.stats + 2, (unsigned long long)st_union);
+            if (st_border) atomicAdd(A.stats + 3, (unsigned long long)st_border);
+        }
+    }
     if (MODE == 0) {
         A.defer_cnt[dq_wave * 64 + lane] = dq_n;
+        {
+            int qs = dq_n;   // queued tests of this wave -> stats[0]
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) qs += __shfl_xor(qs, o);
+            if (lane == 0 && qs) atomicAdd(A.stats + 0, (unsigned long long)qs);
+        }
         cntd += __shfl_xor(cntd, 32);   // the two lane halves saw different rows of the same point
         if (h == 0 && cntd) atomicAdd(A.cnt + my, cntd);
     }
@@ -796,8 +818,7 @@ __global__ __launch_bounds__(256) void cl_resolve_kernel(const float *__restrict
     if (wave >= nwaves || slot >= qcnt[wave * 64 + lane]) return;
     const long wg = wave / CL_NW;                          // blockIdx.y * gridDim.x + blockIdx.x of the pair pass
     const long my = ((wg % nrowblk) * CL_NW + wave % CL_NW) * 32 + (lane & 31);
-    const long other = q[e];
-    atomicAdd(stats + 0, 1ull);
+    const long other = q[e];   // (counted in stats[0] by the pair pass: one atomic per wave there, not one per wave here)
     if (cl_exact_within(Xp, G, my, other, eps2)) atomicAdd(cnt + my, 1);
 }
 
@@ -836,26 +857,42 @@ __global__ __launch_bounds__(1024) void cl_rank_kernel(int *__restrict__ parent,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
-    for (long s = 0; s < N; s += 1024) {
-        const long i = s + threadIdx.x;
-        int root = 0, slot = (int)i;
-        if (owner) {
-            if (i < N) {
-                slot = owner[i];
-                root = slot >= 0;
+    constexpr int PT = 8;   // consecutive indices per thread: a single workgroup walks N in N / 8192 steps
+    for (long s = 0; s < N; s += 1024 * PT) {
+        const long i0 = s + (long)threadIdx.x * PT;
+        int slot[PT];
+        unsigned rootm = 0;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const long i = i0 + j;
+            slot[j] = (int)i;
+            bool root = false;
+            if (owner) {
+                if (i < N) {
+                    slot[j] = owner[i];
+                    root = slot[j] >= 0;
+                }
+            } else if (i < N && core[i]) {
+                const int r = cl_find(parent, (int)i);
+                parent[i] = r;                       // flattened: every core point names its root
+                root = (r == (int)i);
             }
-        } else if (i < N && core[i]) {
-            const int r = cl_find(parent, (int)i);
-            parent[i] = r;                       // flattened: every core point names its root
-            root = (r == (int)i);
+            rootm |= (unsigned)root << j;
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(root);
-        const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __builtin_popcountll(m);
+        const int mine = __builtin_popcount(rootm);
+        int incl = mine;                             // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        int off = base;
+        int off = base + incl - mine;
         for (int w = 0; w < wave; ++w) off += wsum[w];
-        if (root) rank[slot] = off + before + 1;
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+            if (rootm >> j & 1) rank[slot[j]] = ++off;
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0;
@@ -892,7 +929,9 @@ __global__ __launch_bounds__(256) void cl_label_kernel(const int *__restrict__ p
 __global__ __launch_bounds__(256) void cl_minorig_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
                                                          const int *__restrict__ perm, long N, int *__restrict__ minorig) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < N && core[i]) atomicMin(minorig + parent[i], perm[i]);
+    if (i >= N || !core[i]) return;
+    int *slot = minorig + parent[i];
+    if (perm[i] < CL_LD(slot)) atomicMin(slot, perm[i]);   // the minimum only falls: a stale read errs towards an atomic too many
 }
 __global__ __launch_bounds__(256) void cl_owner_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core, long N,
                                                        const int *__restrict__ minorig, int *__restrict__ owner) {

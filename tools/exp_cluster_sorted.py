@@ -1,10 +1,11 @@
-"""Experiment: cluster rows in the order of a sign code of random projections (the locality the block pruning
-needs) instead of the given order.  Times cluster_embeddings on given vs code-sorted rows."""
+"""Experiment: working orders for the clustering passes, applied outside the library (P2N_CL_SORT=0 inside):
+code order vs code order with rows of rare codes (runs shorter than m) moved to the end."""
 import os, sys, time
+os.environ["P2N_CL_SORT"] = "0"
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-from pointcloudsegmentation_amd.clustering import cluster_embeddings, last_cluster_stats
+from pointcloudsegmentation_amd.clustering import cluster_embeddings
 from pointcloudsegmentation_amd.synth import make_embeddings
 from pointcloudsegmentation_amd.inference import preprocess_point_cloud
 from src.models.point2net import Point2Net
@@ -19,34 +20,41 @@ def timed(fn, steps=5):
     return 1e3 * (time.perf_counter() - t0) / steps, r
 
 
-def code_order(e, bits=32, seed=5):
+def code_keys(e, bits=32, seed=5):
     g = torch.Generator(device="cpu").manual_seed(seed)
     r = (torch.randint(0, 2, (e.shape[1], bits), generator=g).float() * 2 - 1).to(e.device)
     s = (e @ r) > 0
     w = (2 ** torch.arange(bits - 1, -1, -1, dtype=torch.int64, device=e.device))
-    key = (s.long() * w).sum(1)
-    return torch.sort(key, stable=True).indices
+    return (s.long() * w).sum(1)
+
+
+def orders(e, m):
+    key = code_keys(e)
+    ks, p = torch.sort(key, stable=True)
+    # run length of every sorted position
+    head = torch.ones_like(ks, dtype=torch.bool); head[1:] = ks[1:] != ks[:-1]
+    rid = torch.cumsum(head.long(), 0) - 1
+    rl = torch.bincount(rid)[rid]
+    rare = rl < m
+    p2 = torch.cat([p[~rare], p[rare]])
+    return p, p2, float(rare.float().mean())
 
 
 n = 166499
-cases = {"33 clusters, random order": torch.from_numpy(make_embeddings(n, 64, 11)).cuda(),
-         "33 clusters, runs": torch.from_numpy(make_embeddings(n, 64, 11, order="runs")).cuda()}
+cases = {"33 clusters, random order": torch.from_numpy(make_embeddings(n, 64, 11)).cuda()}
 rng = np.random.default_rng(0)
 pts = (rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64)
 col = rng.integers(0, 256, (n, 3)).astype(np.float64)
 w = dict(np.load(os.path.join(REPO, "tests", "golden", "weights.npz")))
-m = Point2Net(feature_dim=6, embedding_dim=64)
-m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
-m = m.cuda().eval()
+m_ = Point2Net(feature_dim=6, embedding_dim=64)
+m_.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+m_ = m_.cuda().eval()
 feat, _, _ = preprocess_point_cloud(torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda())
 with torch.no_grad():
-    cases["model embeddings of a random scene"] = m(feat)[0].contiguous()
+    cases["model embeddings of a random scene"] = m_(feat)[0].contiguous()
 for name, e in cases.items():
-    t0, lab0 = timed(lambda: cluster_embeddings(e))
-    for bits in (16, 32):
-        p = code_order(e, bits)
-        es = e[p].contiguous()
-        t1, lab1 = timed(lambda: cluster_embeddings(es))
-        same = bool(((lab0[p] > 0) == (lab1 > 0)).all())
-        print(f"{name:38s} given order {t0:7.2f} ms   sorted by {bits}-bit code {t1:7.2f} ms   clusters {int(lab0.max())} / {int(lab1.max())}"
-              f"  noise sets equal {same}", flush=True)
+    for m in (4, 8, 32):
+        p, p2, frac = orders(e, m)
+        t1, _ = timed(lambda: cluster_embeddings(e[p].contiguous()))
+        t2, _ = timed(lambda: cluster_embeddings(e[p2].contiguous()))
+        print(f"{name:38s} code order {t1:6.2f} ms   rare codes (run < {m}, {100*frac:4.1f} % of rows) last {t2:6.2f} ms", flush=True)
