@@ -226,7 +226,6 @@ struct ClArgs {
     const int *act_cnt;     // per 256-point row block (one workgroup): number of active 128-point blocks
     const int *act_list;    // [row block][nb128]: their indices, ascending
     int nb128;
-    int list_cap;           // pass 2: at most this many entries of a row block's list (the seeding launch), 0 = all
     unsigned char *hit;     // pass 1 writes [row block][nb128]: 1 where some pair of the two blocks came within the "maybe" threshold
     unsigned long long *stats;   // [0] exact tests pass 1, [1] exact tests pass 2, [2] unite calls, [3] border appends
     // pass 1: undecided pairs are queued per lane ([wave][slot][lane] = partner index) and decided by
@@ -272,8 +271,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     // The streamed blocks of this row block come from its active list: 128-point blocks whose bounding
     // sphere can reach ours within eps (cl_active_kernel); everything else is skipped without a load.
     constexpr int SUB = 128 / JB;         // streamed blocks per 128-point block
-    int total = A.act_cnt[blockIdx.x];
-    if (MODE == 1 && A.list_cap > 0 && total > A.list_cap) total = A.list_cap;
+    const int total = A.act_cnt[blockIdx.x];
     const int e0 = (int)((long)total * blockIdx.y / A.nsplit), e1 = (int)((long)total * (blockIdx.y + 1) / A.nsplit);
     const long len = (long)(e1 - e0) * SUB;
     if (len <= 0) return;
@@ -424,7 +422,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                     if (mycore) {
                         pi = cl_unite(A.parent, (int)my, (int)other);
                         ++st_union;
-                    } else if (A.list_cap == 0) {   // (the seeding launch leaves the border lists to the full pass: no duplicates)
+                    } else {
                         ++st_border;
                         const int slot = atomicAdd(A.nbr_cnt + my, 1);
                         if (slot < A.cap) A.nbr[my * A.cap + slot] = (int)other;
@@ -838,7 +836,7 @@ __global__ __launch_bounds__(256) void cl_prepare_link_kernel(const int *__restr
     if (k) blk_has_core[i >> 7] = 1;   // benign race: everybody writes 1
 }
 
-// between the seeding launch and the full link pass: every core point names its root
+// every core point names its root (before the sets are numbered by the caller's indices)
 __global__ __launch_bounds__(256) void cl_flatten_kernel(int *__restrict__ parent, const unsigned char *__restrict__ core, long N) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N || !core[i]) return;
@@ -929,9 +927,22 @@ __global__ __launch_bounds__(256) void cl_label_kernel(const int *__restrict__ p
 __global__ __launch_bounds__(256) void cl_minorig_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
                                                          const int *__restrict__ perm, long N, int *__restrict__ minorig) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N || !core[i]) return;
-    int *slot = minorig + parent[i];
-    if (perm[i] < CL_LD(slot)) atomicMin(slot, perm[i]);   // the minimum only falls: a stale read errs towards an atomic too many
+    const bool in = i < N && core[i];
+    const int r = in ? parent[i] : -1;
+    int v = in ? perm[i] : 0x7fffffff;
+    // neighbours in the working order mostly share a root: the wave's lanes that name the first lane's root send one
+    // atomic between them, the others their own
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+    if (!m) return;
+    const int r0 = __builtin_amdgcn_readlane(r, __builtin_ctzll(m));
+    const bool same = in && r == r0;
+    int w = same ? v : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int u = __shfl_xor(w, o);
+        w = u < w ? u : w;
+    }
+    if (same ? (threadIdx.x & 63) == __builtin_ctzll(m) : in) atomicMin(minorig + r, same ? w : v);
 }
 __global__ __launch_bounds__(256) void cl_owner_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core, long N,
                                                        const int *__restrict__ minorig, int *__restrict__ owner) {
@@ -1063,11 +1074,6 @@ static bool p2n_cluster_refines() {
     return !(e && atoi(e) == 0);
 }
 
-static int p2n_cluster_seed_blocks() {
-    static const int v = [] { const char *e = getenv("P2N_CL_SEED"); return e ? atoi(e) : 1; }();
-    return v;
-}
-
 template <int G, int CT>
 static int cl_launch_pairs(int mode, const ClArgs &a, long nrowblk, hipStream_t stream) {
     const size_t ldsb = (CL_LDS_FLOATS + CL_SLIST_MAX) * sizeof(float);   // 107 KiB: above the default dynamic-LDS limit
@@ -1159,7 +1165,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const long nrowblk = Npad / CL_ROWBLK;
     a.nsplit = cl_nsplit(Npad, G);
     a.defer_q = w.defer_q; a.defer_cnt = w.defer_cnt; a.defer_cap = CL_DEFER_CAP;
-    a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128; a.hit = w.hit; a.list_cap = 0;
+    a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128; a.hit = w.hit;
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
     if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, nrowblk, stream);
@@ -1181,21 +1187,6 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     ps = p2n_prof_begin(P2N_K_CLUSTER_LINK, stream);
     hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, (const unsigned char *)nullptr, nb128, w.act_cnt,
                        w.act_list);
-    // Seeding launch: every row block meets only the first few blocks of its list.  Lists ascend, so the row blocks
-    // of one instance all meet the instance's lowest blocks and hang themselves under the same roots; after the
-    // flattening the full pass below finds staged parent == own parent for nearly every edge and streams through
-    // (it still sees every edge: the seeding only saves it the calls).
-    const int seed = p2n_cluster_seed_blocks();
-    if (seed > 0) {
-        ClArgs s2 = a;
-        s2.list_cap = seed;
-        s2.nsplit = 1;
-        if (G == 8) rc = cl_launch_pairs<8, 4>(1, s2, nrowblk, stream);
-        else if (G == 16) rc = cl_launch_pairs<16, 2>(1, s2, nrowblk, stream);
-        else rc = cl_launch_pairs<32, 1>(1, s2, nrowblk, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(cl_flatten_kernel, dim3(nb256), dim3(256), 0, stream, w.parent, w.core, N);
-    }
     if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, nrowblk, stream);
     else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, nrowblk, stream);
     else rc = cl_launch_pairs<32, 1>(1, a, nrowblk, stream);
