@@ -350,6 +350,11 @@ int p2n_gather_xyz(const float *xyz, int ldx, const int32_t *idx, int B, int N, 
  * border points join the lowest-numbered cluster among their core neighbours) and the
  * reference's relabelling: labels (N) int32, 0 = noise, clusters 1..K; *num_clusters = K
  * (device pointer, may be NULL).  eps is a double because the reference passes a Python float.
+ * Internally the rows are worked on in the order of a 32-bit code of their embeddings (block
+ * pruning needs rows that are close in the embedding to be close in the index); results do not
+ * depend on it: labels, cluster numbers and counts refer to the caller's row indices.
+ * Environment: P2N_CL_SORT=0 works in the given order, P2N_CL_REACH=0 prunes by bounding spheres
+ * only (both read per call; for tests and A/B timings).
  * p2n_cluster_counts copies out the neighbourhood sizes the last call left in `workspace`. */
 int p2n_normalize_rows(const float *emb, long N, int D, float *out, void *stream);
 size_t p2n_cluster_workspace_bytes(long N, int D, int min_samples);
