@@ -670,6 +670,7 @@ __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict_
 // of the outliers is near the instance.  One workgroup per block A (thread = point), the listed centres staged
 // through LDS eight at a time; fp32 dot products with CL_REACH_SLACK on the squared distance.
 #define CL_REACH_TB 16
+#define CL_REACH_SPLIT 4   // workgroups per block A, taking the list's tiles in turn
 #define CL_REACH_SLACK 4e-5f   // > 256 * 2^-24 * 2 (fp32 dot of unit-length vectors, twice in d^2) + the roundings of the three terms
 template <int NCH>
 __global__ __launch_bounds__(128) void cl_reach_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
@@ -715,12 +716,16 @@ __global__ __launch_bounds__(128) void cl_reach_kernel(const float *__restrict__
             c2[buf][t] = B >= 0 ? csq[B] : 0.f;
         }
     };
+    // gridDim.y workgroups share a block's list tile by tile: an outlier block lists every block, and one
+    // workgroup walking all of them alone set the kernel's duration
+    const int first = blockIdx.y * CL_REACH_TB, step = gridDim.y * CL_REACH_TB;
+    if (first >= total) return;
     if (NCH == 1) load_x(0);
-    if (total > 0) stage(0, 0);
+    stage(first, 0);
     __syncthreads();
     int buf = 0;
-    for (int e0 = 0; e0 < total; e0 += CL_REACH_TB, buf ^= 1) {
-        if (e0 + CL_REACH_TB < total) stage(e0 + CL_REACH_TB, buf ^ 1);
+    for (int e0 = first; e0 < total; e0 += step, buf ^= 1) {
+        if (e0 + step < total) stage(e0 + step, buf ^ 1);
         float acc[CL_REACH_TB];
 #pragma unroll
         for (int b = 0; b < CL_REACH_TB; ++b) acc[b] = 0.f;
@@ -1136,13 +1141,13 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     if (p2n_cluster_refines()) {
         P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));
         if (G == 8)
-            hipLaunchKernelGGL(cl_reach_kernel<1>, dim3(nb128), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
+            hipLaunchKernelGGL(cl_reach_kernel<1>, dim3(nb128, CL_REACH_SPLIT), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
                                w.act_cnt, w.act_list, w.reach);
         else if (G == 16)
-            hipLaunchKernelGGL(cl_reach_kernel<2>, dim3(nb128), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
+            hipLaunchKernelGGL(cl_reach_kernel<2>, dim3(nb128, CL_REACH_SPLIT), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
                                w.act_cnt, w.act_list, w.reach);
         else
-            hipLaunchKernelGGL(cl_reach_kernel<4>, dim3(nb128), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
+            hipLaunchKernelGGL(cl_reach_kernel<4>, dim3(nb128, CL_REACH_SPLIT), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
                                w.act_cnt, w.act_list, w.reach);
         hipLaunchKernelGGL(cl_relist_kernel, dim3(nb128 / 2), dim3(256), 0, stream, (const unsigned char *)nullptr, (const int *)nullptr,
                            w.reach, nb128, w.act_cnt, w.act_list);
