@@ -418,6 +418,39 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def scene_leg(device, model, steps=5):
+    """BASELINE.json configs[0]: one reference-sized scene (166,499 points) through inference.predict -- normalise ->
+    forward -> embedding clustering (reference inference.py:76-188) -- and the clustering alone on two kinds of rows."""
+    from pointcloudsegmentation_amd.clustering import cluster_embeddings
+    from pointcloudsegmentation_amd.inference import predict
+    from pointcloudsegmentation_amd.synth import make_embeddings
+    n = 166_499
+    rng = np.random.default_rng(0)
+    pts = (rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64)
+    col = rng.integers(0, 256, (n, 3)).astype(np.float64)
+
+    def timed(fn):
+        fn(); fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize(device)
+        return 1e3 * (time.perf_counter() - t0) / steps, r
+    out = {"workload": "one 166,499-point scene, normalise + forward + DBSCAN(eps 0.1, min_samples 50) + relabel", "n": n}
+    out["ms_host_arrays_in_host_labels_out"], res = timed(lambda: predict(model, pts, col))
+    pg, cg = torch.from_numpy(pts).to(device), torch.from_numpy(col).to(device)
+    out["ms_device_resident"], _ = timed(lambda: predict(model, pg, cg, to_host=False))
+    out["num_instances"] = int(res["num_instances"])
+    for order in ("random", "runs"):
+        e = torch.from_numpy(make_embeddings(n, 64, 11, order=order)).to(device)
+        out[f"cluster_ms_33_instances_rows_{order}"], lab = timed(lambda: cluster_embeddings(e))
+    out["clusters"] = int(lab.max())
+    out["note"] = ("the clustering works on the rows in the order of a code of their embeddings, so the caller's row order "
+                   "does not matter (DESIGN.md section 10); labels bit-identical to scikit-learn's on the golden fixtures")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -427,7 +460,7 @@ def main():
     ap.add_argument("--no-fps", action="store_true", help="skip the FPS leg")
     ap.add_argument("--no-hier", action="store_true", help="skip the hierarchical-sibling leg")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
-    ap.add_argument("--no-scenes", action="store_true", help="skip the scene-stream leg (N > 1 only)")
+    ap.add_argument("--no-scenes", action="store_true", help="skip the scene legs (one scene at N = 1, the stream at N > 1)")
     args = ap.parse_args()
 
     if os.environ.get("P2N_BENCH_WATCHDOG"):      # debugging aid: dump every thread's Python stack if still running after N seconds
@@ -563,6 +596,8 @@ def main():
                 ser = bench_hier.run(B_PER_GPU, N_POINTS, iters=20, serial=True)
                 out["hier"]["mlp_without_corunning_geometry"] = ser["mlp"]
                 out["hier"]["ms_per_forward_wall_one_stream"] = ser["ms_per_forward_wall"]
+            if not args.no_scenes:
+                out["scene"] = scene_leg(device, model)
             if not args.no_cpu:
                 port, tcpu = cpu_baselines(x_np)
                 out["cpu_baseline"] = tcpu
