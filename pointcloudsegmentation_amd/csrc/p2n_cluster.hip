@@ -222,7 +222,10 @@ struct ClArgs {
     const int *colblk_has_core;   // pass 2: per block of 128 columns
     int *nbr_cnt, *nbr;     // pass 2: core neighbours of non-core rows, `cap` slots per row
     int cap;
-    int nsplit;
+    // the pass's work list (cl_plan_kernel): chunk k = entries [work_e0[k], + work_meta[1]) of row block work_rb[k]'s list;
+    // work_meta[0] chunks in all, one workgroup each
+    const int *work_rb, *work_e0, *work_meta;
+    int nsplit;   // pass 2: workgroups per row block
     const int *act_cnt;     // per 256-point row block (one workgroup): number of active 128-point blocks
     const int *act_list;    // [row block][nb128]: their indices, ascending
     int nb128;
@@ -249,6 +252,7 @@ struct ClArgs {
 #define CL_PAR_BASE (CL_RING * CL_BLK_FLOATS)   // then three rotating parent[128] slots (pass 2)
 #define CL_PU_BASE (CL_PAR_BASE + 3 * 128)       // then per parent slot: the common parent of each fetching wave's columns
 #define CL_LDS_FLOATS (CL_PU_BASE + 8)
+#define CL_CHUNK_MIN 8      // shortest chunk of a list a workgroup is started for (cl_plan_kernel)
 #define CL_SLIST_MAX 2048   // active-list entries one workgroup may hold in LDS (after the ring)
 
 #define CL_NW 8   // waves per workgroup, one workgroup per CU: 256 wave-owned points share one streamed block
@@ -265,25 +269,39 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     constexpr int EL = UT * 16;           // pairs per lane per unit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const long i0 = ((long)blockIdx.x * CL_NW + wave) * 32;
+    // Pass 1 takes chunk blockIdx.x of the work list (the grid is the host's bound on the number of chunks).  Pass 2
+    // keeps one workgroup per (row block, nsplit-th of its list), the grid row-block-fastest: workgroups of one
+    // row block then run one after the other rather than side by side, each starting from the parents the last left
+    // (side by side, every one of them unites the same rows again: 29 M -> 84 M union attempts, 1.3 -> 3.1 ms).
+    const int chunk = blockIdx.x;
+    if (MODE == 0 && chunk >= A.work_meta[0]) return;
+    const int rb = MODE == 0 ? A.work_rb[chunk] : (int)blockIdx.x;   // this workgroup's 256 rows
+    const long i0 = ((long)rb * CL_NW + wave) * 32;
     const long my = i0 + c;               // the point this lane owns
 
     // The streamed blocks of this row block come from its active list: 128-point blocks whose bounding
     // sphere can reach ours within eps (cl_active_kernel); everything else is skipped without a load.
     constexpr int SUB = 128 / JB;         // streamed blocks per 128-point block
-    const int total = A.act_cnt[blockIdx.x];
-    const int e0 = (int)((long)total * blockIdx.y / A.nsplit), e1 = (int)((long)total * (blockIdx.y + 1) / A.nsplit);
+    const int total = A.act_cnt[rb];
+    int e0, e1;
+    if (MODE == 0) {
+        e0 = A.work_e0[chunk];
+        e1 = e0 + A.work_meta[1] < total ? e0 + A.work_meta[1] : total;
+    } else {
+        e0 = (int)((long)total * blockIdx.y / A.nsplit);
+        e1 = (int)((long)total * (blockIdx.y + 1) / A.nsplit);
+    }
     const long len = (long)(e1 - e0) * SUB;
     if (len <= 0) return;
     int *slist = reinterpret_cast<int *>(lds + CL_LDS_FLOATS);   // this workgroup's slice of the list
-    for (int i = threadIdx.x; i < e1 - e0; i += CL_NW * 64) slist[i] = A.act_list[(long)blockIdx.x * A.nb128 + e0 + i];
+    for (int i = threadIdx.x; i < e1 - e0; i += CL_NW * 64) slist[i] = A.act_list[(long)rb * A.nb128 + e0 + i];
     if (MODE == 1 && threadIdx.x < 8) lds[CL_PU_BASE + threadIdx.x] = __int_as_float(-1);   // pass 2, a wave that stages no parents: "no core point"
     __syncthreads();
     auto jbof = [&](long pos) -> long { return (long)slist[pos / SUB] * SUB + pos % SUB; };
     // Pass 1: every workgroup walks the blocks in the same order (a block is fetched from HBM once per
     // XCD, then served from its L2).  Pass 2: staggered starts spread the union-find merges instead of
     // piling every workgroup onto one block's roots at the same time.
-    long cur = MODE == 0 ? 0 : ((long)blockIdx.x * (CL_NW * 32 / JB)) % len;
+    long cur = MODE == 0 ? 0 : ((long)rb * (CL_NW * 32 / JB)) % len;
 
     auto stage = [&](long jb, int buf) {
         float *dst = lds + buf * CL_BLK_FLOATS;
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         if (lane == 0) lds[CL_PU_BASE + wave - 2] = __int_as_float(cp);
     }
     int pnext = 0;
-    int pi_nxt = MODE == 1 ? CL_LD(A.parent + (((long)blockIdx.x * CL_NW + wave) * 32 + (lane & 31))) : 0;
+    int pi_nxt = MODE == 1 ? CL_LD(A.parent + (((long)rb * CL_NW + wave) * 32 + (lane & 31))) : 0;
 
     constexpr int KS = G / 2;             // k-steps of 16
     constexpr int NSL = 3 * KS;           // MFMA slots per tile: hi.hi, hi.lo, lo.hi per k-step
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     const float hm = hh - 0.5f * A.tau, hd = hh + 0.5f * A.tau;
     const bool mycore = MODE == 1 && A.core[my];
     int dq_n = 0;   // pass 1: queued undecided pairs of this lane
-    const long dq_wave = ((long)blockIdx.y * gridDim.x + blockIdx.x) * CL_NW + wave;
+    const long dq_wave = (long)chunk * CL_NW + wave;
     int cntd = 0, cntm = 0, expdiff = 0;   // pass 1: definite(+resolved) / maybe counts; pass 2: cntm = maybe-edges seen
     int pi = 0;
     // pass 2: diagnostics counters, flushed once per wave at the end (an atomic per event on one shared word was a
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             // a candidate pair, so the common case of a unit without any costs one vote.
             if (MODE == 0) {
                 if (__builtin_amdgcn_ballot_w64(cntm != before)) {
-                    if (lane == 0) A.hit[(long)blockIdx.x * A.nb128 + (col0_prev >> 7)] = 1;
+                    if (lane == 0) A.hit[(long)rb * A.nb128 + (col0_prev >> 7)] = 1;
                     if (__builtin_amdgcn_ballot_w64(cntm - cntd != expdiff)) {
                         slow_unit(accp, par_prev, u_prev, col0_prev);
                         expdiff = cntm - cntd;
@@ -804,6 +822,64 @@ __global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__r
     if (t == 0) act_cnt[ib] = base;
 }
 
+// The work list of a pair pass.  Lists differ wildly in length (an outlier block meets hundreds of blocks, an instance
+// block a few dozen), so a workgroup per row block -- or per fixed fraction of one -- leaves the chip waiting for the
+// longest.  Lists are cut into chunks of CH entries, CH chosen so that the chunks fill at most `kslots` + one per row
+// block of the grid the host launches; a workgroup takes one chunk.
+__global__ __launch_bounds__(1024) void cl_plan_kernel(const int *__restrict__ act_cnt, int nrowblk, int kslots,
+                                                       int *__restrict__ work_rb, int *__restrict__ work_e0,
+                                                       int *__restrict__ work_meta) {
+    __shared__ long long tsum[16];
+    __shared__ int wsum[16];
+    __shared__ int base, ch_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    long long tot = 0;
+    for (int i = t; i < nrowblk; i += 1024) tot += act_cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) tsum[wave] = tot;
+    __syncthreads();
+    if (t == 0) {
+        long long all = 0;
+        for (int w = 0; w < 16; ++w) all += tsum[w];
+        long long ch = (all + kslots - 1) / kslots;
+        ch = ch < CL_CHUNK_MIN ? CL_CHUNK_MIN : (ch > CL_SLIST_MAX ? CL_SLIST_MAX : ch);
+        ch_s = (int)ch;
+        base = 0;
+    }
+    __syncthreads();
+    const int CH = ch_s;
+    for (int s0 = 0; s0 < nrowblk; s0 += 1024) {
+        const int i = s0 + t;
+        const int n = i < nrowblk ? (act_cnt[i] + CH - 1) / CH : 0;
+        int incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int off = base + incl - n;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        for (int c = 0; c < n; ++c) {
+            work_rb[off + c] = i;
+            work_e0[off + c] = c * CH;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int all = 0;
+            for (int w = 0; w < 16; ++w) all += wsum[w];
+            base += all;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        work_meta[0] = base;
+        work_meta[1] = CH;
+    }
+}
+
 // ------------------------------------------------------------------ deferred exact tests of pass 1
 // One thread per queue slot ([wave][slot][lane]).  The pair passes run their 8 waves in lockstep (a
 // barrier per streamed block), so a wave that stops for a float64 test -- two dependent memory round
@@ -811,16 +887,15 @@ __global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__r
 // in flight at once.
 __global__ __launch_bounds__(256) void cl_resolve_kernel(const float *__restrict__ Xp, int G, double eps2,
                                                          const int *__restrict__ q, const int *__restrict__ qcnt, int cap,
-                                                         long nwaves, int nrowblk, int *__restrict__ cnt,
-                                                         unsigned long long *__restrict__ stats) {
+                                                         long nwaves, const int *__restrict__ work_rb,
+                                                         const int *__restrict__ work_meta, int *__restrict__ cnt) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;   // ((wave * cap) + slot) * 64 + lane
     const int lane = (int)(e & 63);
     const long ws = e >> 6;
     const long wave = ws / cap;
     const int slot = (int)(ws % cap);
-    if (wave >= nwaves || slot >= qcnt[wave * 64 + lane]) return;
-    const long wg = wave / CL_NW;                          // blockIdx.y * gridDim.x + blockIdx.x of the pair pass
-    const long my = ((wg % nrowblk) * CL_NW + wave % CL_NW) * 32 + (lane & 31);
+    if (wave >= nwaves || wave / CL_NW >= work_meta[0] || slot >= qcnt[wave * 64 + lane]) return;
+    const long my = ((long)work_rb[wave / CL_NW] * CL_NW + wave % CL_NW) * 32 + (lane & 31);   // wave / CL_NW: the pair pass's chunk
     const long other = q[e];   // (counted in stats[0] by the pair pass: one atomic per wave there, not one per wave here)
     if (cl_exact_within(Xp, G, my, other, eps2)) atomicAdd(cnt + my, 1);
 }
@@ -977,18 +1052,31 @@ struct ClWs {
     size_t sort_tmp_bytes;
     int *defer_q, *defer_cnt;
     long defer_waves;
+    int *work_rb, *work_e0, *work_meta;
+    int kslots, kbound;   // chunks the plan may fill beyond one per row block; the pair passes' grid
 };
 
 #define CL_DEFER_CAP 16   // queued undecided pairs per lane (pass 1); beyond that a lane decides on the spot
 
-// column splits of the pair passes: enough workgroups to fill the chip several times, a list slice must fit in LDS
-static int cl_nsplit(long Npad, int G) {
-    const int CT = 32 / G;
-    const long nrowblk = Npad / CL_ROWBLK, ncolblk = Npad / (CT * 32), nb128 = Npad / 128;
+// Grid of the pair passes: `kslots` chunks the plan aims at (enough to fill the chip a dozen times over, and enough
+// that a chunk of the longest possible list fits the LDS slice) plus one partial chunk per row block.
+// pass 2: workgroups per row block -- enough to fill the chip several times, and a slice of the longest list fits in LDS
+static int cl_nsplit(long Npad) {
+    const long nrowblk = Npad / CL_ROWBLK, nb128 = Npad / 128;
     long ns = (2048 + nrowblk - 1) / nrowblk;
-    ns = ns < 1 ? 1 : (ns > ncolblk ? ncolblk : ns);
+    ns = ns < 1 ? 1 : (ns > nb128 ? nb128 : ns);
     if (ns * CL_SLIST_MAX < nb128) ns = (nb128 + CL_SLIST_MAX - 1) / CL_SLIST_MAX;
     return (int)ns;
+}
+
+static void cl_chunks(long Npad, int &kslots, int &kbound) {
+    const long nrowblk = Npad / CL_ROWBLK, nb128 = Npad / 128;
+    long k = 8 * nrowblk;
+    k = k < 256 ? 256 : (k > 4096 ? 4096 : k);
+    const long kmin = nrowblk * ((nb128 + CL_SLIST_MAX - 1) / CL_SLIST_MAX);
+    if (k < kmin) k = kmin;
+    kslots = (int)k;
+    kbound = (int)(k + nrowblk);
 }
 
 static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
@@ -1028,7 +1116,11 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
     w.owner = (int *)take(sizeof(int) * Npad);
     w.sort_tmp_bytes = (size_t)Npad * 8 + (4u << 20);   // the double-buffered radix sort needs its digit counts only; checked at the call
     w.sort_tmp = take(w.sort_tmp_bytes);
-    w.defer_waves = (Npad / CL_ROWBLK) * cl_nsplit(Npad, G) * CL_NW;
+    cl_chunks(Npad, w.kslots, w.kbound);
+    w.work_rb = (int *)take(sizeof(int) * w.kbound);
+    w.work_e0 = (int *)take(sizeof(int) * w.kbound);
+    w.work_meta = (int *)take(sizeof(int) * 4);
+    w.defer_waves = (long)w.kbound * CL_NW;
     w.defer_q = (int *)take(sizeof(int) * (size_t)w.defer_waves * CL_DEFER_CAP * 64);
     w.defer_cnt = (int *)take(sizeof(int) * (size_t)w.defer_waves * 64);
     return o;
@@ -1080,16 +1172,17 @@ static bool p2n_cluster_refines() {
 }
 
 template <int G, int CT>
-static int cl_launch_pairs(int mode, const ClArgs &a, long nrowblk, hipStream_t stream) {
+// kbound: pass 1 the bound on the work list's chunks, pass 2 the number of row blocks
+static int cl_launch_pairs(int mode, const ClArgs &a, int kbound, hipStream_t stream) {
     const size_t ldsb = (CL_LDS_FLOATS + CL_SLIST_MAX) * sizeof(float);   // 107 KiB: above the default dynamic-LDS limit
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     if (mode == 0)
-        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 0>), dim3((unsigned)nrowblk, a.nsplit), dim3(CL_NW * 64), ldsb, stream, a);
+        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 0>), dim3((unsigned)kbound), dim3(CL_NW * 64), ldsb, stream, a);
     else
-        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 1>), dim3((unsigned)nrowblk, a.nsplit), dim3(CL_NW * 64), ldsb, stream, a);
+        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 1>), dim3((unsigned)kbound, a.nsplit), dim3(CL_NW * 64), ldsb, stream, a);
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
 }
@@ -1168,14 +1261,15 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     a.cnt = w.cnt; a.parent = w.parent; a.core = w.core; a.colblk_has_core = w.blk_has_core;
     a.nbr_cnt = w.nbr_cnt; a.nbr = w.nbr; a.cap = cap; a.stats = w.stats;
     const long nrowblk = Npad / CL_ROWBLK;
-    a.nsplit = cl_nsplit(Npad, G);
+    a.work_rb = w.work_rb; a.work_e0 = w.work_e0; a.work_meta = w.work_meta;
     a.defer_q = w.defer_q; a.defer_cnt = w.defer_cnt; a.defer_cap = CL_DEFER_CAP;
     a.act_cnt = w.act_cnt; a.act_list = w.act_list; a.nb128 = nb128; a.hit = w.hit;
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
-    if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, nrowblk, stream);
-    else if (G == 16) rc = cl_launch_pairs<16, 2>(0, a, nrowblk, stream);
-    else rc = cl_launch_pairs<32, 1>(0, a, nrowblk, stream);
+    hipLaunchKernelGGL(cl_plan_kernel, dim3(1), dim3(1024), 0, stream, w.act_cnt, (int)nrowblk, w.kslots, w.work_rb, w.work_e0, w.work_meta);
+    if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, w.kbound, stream);
+    else if (G == 16) rc = cl_launch_pairs<16, 2>(0, a, w.kbound, stream);
+    else rc = cl_launch_pairs<32, 1>(0, a, w.kbound, stream);
     p2n_prof_end(ps, stream);
     if (rc) return rc;
 
@@ -1183,7 +1277,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         const long slots = w.defer_waves * CL_DEFER_CAP * 64;
         ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
         hipLaunchKernelGGL(cl_resolve_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, w.Xp, G, a.eps2,
-                           w.defer_q, w.defer_cnt, CL_DEFER_CAP, w.defer_waves, (int)nrowblk, w.cnt, w.stats);
+                           w.defer_q, w.defer_cnt, CL_DEFER_CAP, w.defer_waves, w.work_rb, w.work_meta, w.cnt);
         p2n_prof_end(ps, stream);
     }
     hipLaunchKernelGGL(cl_prepare_link_kernel, dim3(nb256), dim3(256), 0, stream, w.cnt, w.nrm, N, Npad, min_samples, w.core,
@@ -1192,9 +1286,10 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     ps = p2n_prof_begin(P2N_K_CLUSTER_LINK, stream);
     hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, (const unsigned char *)nullptr, nb128, w.act_cnt,
                        w.act_list);
-    if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, nrowblk, stream);
-    else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, nrowblk, stream);
-    else rc = cl_launch_pairs<32, 1>(1, a, nrowblk, stream);
+    a.nsplit = cl_nsplit(Npad);
+    if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, (int)nrowblk, stream);
+    else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, (int)nrowblk, stream);
+    else rc = cl_launch_pairs<32, 1>(1, a, (int)nrowblk, stream);
     p2n_prof_end(ps, stream);
     if (rc) return rc;
 
