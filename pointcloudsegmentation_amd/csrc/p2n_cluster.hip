@@ -880,6 +880,8 @@ __global__ __launch_bounds__(1024) void cl_plan_kernel(const int *__restrict__ a
     }
 }
 
+#define CL_DEFER_CAP 16   // queued undecided pairs per lane (pass 1); beyond that a lane decides on the spot
+#define CL_RESOLVE_SG 4   // queue slots one thread of cl_resolve_kernel works through
 // ------------------------------------------------------------------ deferred exact tests of pass 1
 // One thread per queue slot ([wave][slot][lane]).  The pair passes run their 8 waves in lockstep (a
 // barrier per streamed block), so a wave that stops for a float64 test -- two dependent memory round
@@ -889,15 +891,22 @@ __global__ __launch_bounds__(256) void cl_resolve_kernel(const float *__restrict
                                                          const int *__restrict__ q, const int *__restrict__ qcnt, int cap,
                                                          long nwaves, const int *__restrict__ work_rb,
                                                          const int *__restrict__ work_meta, int *__restrict__ cnt) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;   // ((wave * cap) + slot) * 64 + lane
+    // thread = (wave, slot group, lane): CL_RESOLVE_SG slots each, so that a quarter of the workgroups is started
+    // than with a thread per slot (most queues are empty, and at 152,000 workgroups the launch rate was the cost)
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;   // ((wave * groups) + group) * 64 + lane
     const int lane = (int)(e & 63);
     const long ws = e >> 6;
-    const long wave = ws / cap;
-    const int slot = (int)(ws % cap);
-    if (wave >= nwaves || wave / CL_NW >= work_meta[0] || slot >= qcnt[wave * 64 + lane]) return;
+    const int groups = (cap + CL_RESOLVE_SG - 1) / CL_RESOLVE_SG;
+    const long wave = ws / groups;
+    const int s0 = (int)(ws % groups) * CL_RESOLVE_SG;
+    if (wave >= nwaves || wave / CL_NW >= work_meta[0]) return;
+    const int n = qcnt[wave * 64 + lane];
+    if (s0 >= n) return;
     const long my = ((long)work_rb[wave / CL_NW] * CL_NW + wave % CL_NW) * 32 + (lane & 31);   // wave / CL_NW: the pair pass's chunk
-    const long other = q[e];   // (counted in stats[0] by the pair pass: one atomic per wave there, not one per wave here)
-    if (cl_exact_within(Xp, G, my, other, eps2)) atomicAdd(cnt + my, 1);
+    int add = 0;   // (the tests are counted in stats[0] by the pair pass: one atomic per wave there)
+    for (int s = s0; s < n && s < s0 + CL_RESOLVE_SG; ++s)
+        add += cl_exact_within(Xp, G, my, q[(wave * cap + s) * 64 + lane], eps2);
+    if (add) atomicAdd(cnt + my, add);
 }
 
 // ------------------------------------------------------------------ glue kernels
@@ -1056,7 +1065,6 @@ struct ClWs {
     int kslots, kbound;   // chunks the plan may fill beyond one per row block; the pair passes' grid
 };
 
-#define CL_DEFER_CAP 16   // queued undecided pairs per lane (pass 1); beyond that a lane decides on the spot
 
 // Grid of the pair passes: `kslots` chunks the plan aims at (enough to fill the chip a dozen times over, and enough
 // that a chunk of the longest possible list fits the LDS slice) plus one partial chunk per row block.
@@ -1274,7 +1282,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     if (rc) return rc;
 
     {   // the queued float64 decisions of pass 1 (every lane of the pass wrote its queue length)
-        const long slots = w.defer_waves * CL_DEFER_CAP * 64;
+        const long slots = w.defer_waves * ((CL_DEFER_CAP + CL_RESOLVE_SG - 1) / CL_RESOLVE_SG) * 64;
         ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
         hipLaunchKernelGGL(cl_resolve_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, w.Xp, G, a.eps2,
                            w.defer_q, w.defer_cnt, CL_DEFER_CAP, w.defer_waves, w.work_rb, w.work_meta, w.cnt);
