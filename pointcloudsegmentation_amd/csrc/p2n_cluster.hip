@@ -255,6 +255,7 @@ struct ClArgs {
 #define CL_CHUNK_MIN 8      // shortest chunk of a list a workgroup is started for (cl_plan_kernel)
 #define CL_SLIST_MAX 2048   // active-list entries one workgroup may hold in LDS (after the ring)
 
+#define CL_DENSE_BITS 8   // candidate pairs per lane from which a unit of the link pass counts as dense (slow_unit)
 #define CL_NW 8   // waves per workgroup, one workgroup per CU: 256 wave-owned points share one streamed block
 #define CL_ROWBLK (CL_NW * 32)
 #define CL_NPAD_UNIT 256   // lcm(CL_ROWBLK, 128): rows pad to whole workgroups and whole streamed blocks
@@ -414,6 +415,52 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                     }
                 }
             }
+        if (MODE == 1 && __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(need) >= CL_DENSE_BITS)) >= 16) {
+            // A dense unit: the wave's rows and the unit's columns are one instance's.  Lane by lane every row
+            // would unite with every column -- chains of dependent coherent loads, nearly all of them redundant.
+            // Instead, column by column (the same column for all lanes of a lane half at bit e), one core lane whose
+            // edge is certain without a float64 test leads and unites with the column; every core lane that names
+            // the same parent as the leader is in the leader's set already and leaves both the call and the exact
+            // test out.  The lead rotates with e, so the calls that remain run side by side in different lanes.
+#pragma nounroll
+            for (int e = 0; e < EL; ++e) {
+                const bool mine = need >> e & 1;
+                if (!__builtin_amdgcn_ballot_w64(mine)) continue;
+                const bool certain = mine && (sure >> e & 1);
+                const unsigned long long ms = __builtin_amdgcn_ballot_w64(certain && mycore);
+                const unsigned lo32 = (unsigned)ms, hi32 = (unsigned)(ms >> 32);
+                int l0 = -1, l1 = -1, q0 = 0, q1 = 0;
+                if (lo32) {
+                    l0 = (__builtin_ctz((lo32 >> e) | (lo32 << ((32 - e) & 31))) + e) & 31;   // first certain lane at or after lane e
+                    q0 = __builtin_amdgcn_readlane(pi, l0);
+                }
+                if (hi32) {
+                    l1 = 32 + ((__builtin_ctz((hi32 >> e) | (hi32 << ((32 - e) & 31))) + e) & 31);
+                    q1 = __builtin_amdgcn_readlane(pi, l1);
+                }
+                const int lead = h ? l1 : l0;
+                if (!mine || (mycore && lead >= 0 && lane != lead && pi == (h ? q1 : q0))) continue;
+                const int ut = e >> 4, r = e & 15;
+                const long other = col0 + ut * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (mycore && __float_as_int(par[(u * UT + ut) * 32 + 8 * (r >> 2) + 4 * h + (r & 3)]) == pi) continue;
+                bool ok = certain;
+                if (!ok) {
+                    ok = cl_exact_within(A.Xp, G, my, other, A.eps2);
+                    ++st_exact;
+                }
+                if (ok) {
+                    if (mycore) {
+                        pi = cl_unite(A.parent, (int)my, (int)other);
+                        ++st_union;
+                    } else {
+                        ++st_border;
+                        const int slot = atomicAdd(A.nbr_cnt + my, 1);
+                        if (slot < A.cap) A.nbr[my * A.cap + slot] = (int)other;
+                    }
+                }
+            }
+            return;
+        }
         while (need) {
             const int e = __builtin_ctz(need);
             need &= need - 1;
