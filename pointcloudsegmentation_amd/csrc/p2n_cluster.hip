@@ -729,101 +729,80 @@ __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict_
 }
 
 // The bounding spheres alone prune poorly once a block holds an outlier: its sphere spans everything.  A pair
-// (i in A, j in B) within eps needs i within eps of B's sphere AND j within eps of A's sphere, so per listed pair
-// of blocks this kernel notes whether ANY point of A reaches B's sphere; cl_relist_kernel keeps a block only if
+// (i in A, j in B) within eps needs i within eps of B's sphere AND j within eps of A's sphere, so per pair of blocks
+// cl_reach_kernel notes whether ANY point of A reaches B's sphere; cl_relist_kernel keeps a listed block only if
 // the note holds both ways round.  An outlier block against a tight instance block fails the second half: none
-// of the outliers is near the instance.  One workgroup per block A (thread = point), the listed centres staged
-// through LDS eight at a time; fp32 dot products with CL_REACH_SLACK on the squared distance.
-#define CL_REACH_TB 16
-#define CL_REACH_SPLIT 4   // workgroups per block A, taking the list's tiles in turn
-#define CL_REACH_SLACK 4e-5f   // > 256 * 2^-24 * 2 (fp32 dot of unit-length vectors, twice in d^2) + the roundings of the three terms
-template <int NCH>
-__global__ __launch_bounds__(128) void cl_reach_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
-                                                       const float *__restrict__ centre, const float *__restrict__ radius,
-                                                       const float *__restrict__ csq, int nb, float eps,
-                                                       const int *__restrict__ act_cnt, const int *__restrict__ act_list,
-                                                       unsigned char *__restrict__ reach) {
-    // two tiles of centres in LDS: the next one is staged while this one is used, one barrier per tile
-    __shared__ __attribute__((aligned(16))) float cs[2][CL_REACH_TB][NCH * 64];
-    __shared__ float c2[2][CL_REACH_TB], lim[2][CL_REACH_TB];
-    __shared__ int blk[2][CL_REACH_TB], any[2][2][CL_REACH_TB];
-    const int A = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long i = (long)A * 128 + t;
-    const float nhi = nh[i];
-    const bool real = nhi > -__builtin_inff();
-    const float x2 = real ? -2.f * nhi : 0.f;
-    const float *px = Xp + ((i >> 5) * (8 * NCH) * 64 + (i & 31)) * 4;
-    const int wg = A >> 1, total = act_cnt[wg];
-    const int *list = act_list + (long)wg * nb;
-    constexpr int Dp = 64 * NCH;   // the padded dimension: G = 8 NCH fragments (cl_geometry)
-    f32x4 x[16];
-    auto load_x = [&](int ch) {
+// of the outliers is near the instance.
+#define CL_REACH_SLACK 4e-5f   // on x.c - |c|^2/2: three-term bf16 split (<= 1.5e-5 for unit-length x, |c| <= 1) + fp32 accumulation + roundings of the terms
+// centres as one more row set in the split-bf16 fragment layout of Xb (cl_normalize_kernel), 32 centres per tile, and
+// per centre the accumulator start value (R^2 - |c|^2) / 2, R = radius + eps + margin (-inf: empty block or padding)
+__global__ __launch_bounds__(256) void cl_pack_centres_kernel(const float *__restrict__ centre, const float *__restrict__ radius,
+                                                              int nb, int nbpad, int G, float eps, float *__restrict__ Cb,
+                                                              float *__restrict__ nhc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nbpad) return;
+    const bool live = i < nb && radius[i] >= 0.f;
+    float sq = 0.f;
+    for (int k = 0; k < G * 8; k += 4) {
+        const int ks = k >> 4, hb = (k >> 3) & 1, e0 = k & 4;
+        unsigned short *fh = reinterpret_cast<unsigned short *>(Cb + ((((long)i >> 5) * G + 2 * ks) * 64 + hb * 32 + (i & 31)) * 4);
+        unsigned short *fl = fh + 512;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {   // dims 64 ch + 4 q ..: fragment g = 8 ch + q / 2, half q % 2
-            const int g = 8 * ch + (q >> 1);
-            x[q] = *reinterpret_cast<const f32x4 *>(px + g * 256 + (q & 1) * 128);
+        for (int j = 0; j < 4; ++j) {
+            const float v = live ? centre[(long)i * G * 8 + k + j] : 0.f;
+            sq = fmaf(v, v, sq);
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            fh[e0 + j] = __builtin_bit_cast(unsigned short, hi);
+            fl[e0 + j] = __builtin_bit_cast(unsigned short, lo);
         }
-    };
-    auto stage = [&](int e0, int buf) {
-        for (int q = t; q < CL_REACH_TB * NCH * 16; q += 128) {   // float4 pieces
-            const int b = q / (NCH * 16), k4 = q % (NCH * 16);
-            const int B = e0 + b < total ? list[e0 + b] : -1;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (B >= 0) v = *reinterpret_cast<const f32x4 *>(centre + (long)B * Dp + 4 * k4);
-            *reinterpret_cast<f32x4 *>(&cs[buf][b][4 * k4]) = v;
-        }
-        if (t < CL_REACH_TB) {
-            const int B = e0 + t < total ? list[e0 + t] : -1;
-            blk[buf][t] = B;
-            const float r = B >= 0 ? radius[B] : -1.f;
-            const float R = r + eps + CL_SPH_MARGIN;
-            lim[buf][t] = r >= 0.f ? R * R + CL_REACH_SLACK : -1.f;
-            c2[buf][t] = B >= 0 ? csq[B] : 0.f;
-        }
-    };
-    // gridDim.y workgroups share a block's list tile by tile: an outlier block lists every block, and one
-    // workgroup walking all of them alone set the kernel's duration
-    const int first = blockIdx.y * CL_REACH_TB, step = gridDim.y * CL_REACH_TB;
-    if (first >= total) return;
-    if (NCH == 1) load_x(0);
-    stage(first, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int e0 = first; e0 < total; e0 += step, buf ^= 1) {
-        if (e0 + step < total) stage(e0 + step, buf ^ 1);
-        float acc[CL_REACH_TB];
+    }
+    const float R = live ? radius[i] + eps + CL_SPH_MARGIN : 0.f;
+    nhc[i] = live ? 0.5f * (R * R - sq) : -__builtin_inff();
+}
+
+// One workgroup per block A (wave = 32 of its points, operands in registers as in the pair kernel), every tile of 32
+// centres in turn: D = C . X^T on the matrix pipe (hi.hi + hi.lo + lo.hi), accumulators started at (R^2 - |c|^2) / 2, so
+//   |x - c|^2 <= R^2   <=>   acc >= |x|^2 / 2;
+// a ballot per accumulator register tells whether any of the wave's points reaches that centre's sphere.  Dense
+// (166k points x 1,301 centres x 64 = 28 GFLOP on bf16 MFMAs) it is cheaper than the listed pairs were on the vector ALU.
+template <int G>
+__global__ __launch_bounds__(256) void cl_reach_kernel(const float *__restrict__ Xb, const float *__restrict__ nh,
+                                                       const float *__restrict__ Cb, const float *__restrict__ nhc, int nb,
+                                                       int ntile, unsigned char *__restrict__ reach) {
+    constexpr int KS = G / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const long A = blockIdx.x, i0 = (A * 4 + wave) * 32;
+    cl_bf16x8 ah[KS], al[KS];
 #pragma unroll
-        for (int b = 0; b < CL_REACH_TB; ++b) acc[b] = 0.f;
-#pragma unroll 1
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (NCH > 1) load_x(ch);
+    for (int ks = 0; ks < KS; ++ks) {
+        ah[ks] = *reinterpret_cast<const cl_bf16x8 *>(Xb + ((i0 >> 5) * G + 2 * ks) * 256 + lane * 4);
+        al[ks] = *reinterpret_cast<const cl_bf16x8 *>(Xb + ((i0 >> 5) * G + 2 * ks + 1) * 256 + lane * 4);
+    }
+    const float hx = -nh[i0 + (lane & 31)] - CL_REACH_SLACK;   // |x|^2 / 2 - slack (+inf on pad rows: reaches nothing)
+    for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y) {
+        f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(nhc + jt * 32 + 8 * gq + 4 * h);
 #pragma unroll
-                for (int b = 0; b < CL_REACH_TB; ++b) {
-                    const f32x4 c = *reinterpret_cast<const f32x4 *>(&cs[buf][b][ch * 64 + 4 * q]);
-                    acc[b] = fmaf(x[q][0], c[0], acc[b]);
-                    acc[b] = fmaf(x[q][1], c[1], acc[b]);
-                    acc[b] = fmaf(x[q][2], c[2], acc[b]);
-                    acc[b] = fmaf(x[q][3], c[3], acc[b]);
-                }
-                // one q at a time: left alone the compiler orders the multiply-adds centre by centre, which needs all
-                // 256 staged vectors of a tile in registers at once (hundreds of spills)
-#pragma unroll
-                for (int b = 0; b < CL_REACH_TB; ++b) asm volatile("" : "+v"(acc[b]));
-            }
+            for (int q = 0; q < 4; ++q) acc[4 * gq + q] = v[q];
         }
 #pragma unroll
-        for (int b = 0; b < CL_REACH_TB; ++b) {
-            const float d2 = x2 - 2.f * acc[b] + c2[buf][b];
-            // (no test of lim's sign: a branch on it would pull this centre's whole dot product behind it, and with
-            // it every staged value into registers; an empty block's limit of -1 lies below any d2)
-            const bool ok = real & (d2 <= lim[buf][b]);
-            const bool hit = __builtin_amdgcn_ballot_w64(ok) != 0;
-            if (lane == 0) any[buf][wave][b] = hit;
+        for (int ks = 0; ks < KS; ++ks) {
+            const cl_bf16x8 bh = *reinterpret_cast<const cl_bf16x8 *>(Cb + ((long)jt * G + 2 * ks) * 256 + lane * 4);
+            const cl_bf16x8 bl = *reinterpret_cast<const cl_bf16x8 *>(Cb + ((long)jt * G + 2 * ks + 1) * 256 + lane * 4);
+            acc = MFMAB(bh, ah[ks], acc);
+            acc = MFMAB(bh, al[ks], acc);
+            acc = MFMAB(bl, ah[ks], acc);
         }
-        __syncthreads();   // the votes of both waves; the next tile is staged; everybody has left the tile before this one
-        if (t < CL_REACH_TB && blk[buf][t] >= 0) reach[(long)A * nb + blk[buf][t]] = (unsigned char)(any[buf][0][t] | any[buf][1][t]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(acc[r] >= hx);
+            const unsigned half = h ? (unsigned)(m >> 32) : (unsigned)m;   // the two lane halves hold different centres
+            const int col = jt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if ((lane & 31) == 0 && half && col < nb) reach[A * nb + col] = 1;   // four waves may write the same 1
+        }
     }
 }
 
@@ -1099,6 +1078,7 @@ struct ClWs {
     unsigned char *core;
     unsigned long long *stats;
     float *centre, *radius, *csq;
+    float *Cb, *nhc;   // centres in the fragment layout of Xb, and their accumulator start values (cl_pack_centres_kernel)
     int *act_cnt, *act_list;
     unsigned char *hit, *reach;
     unsigned *key_a, *key_b;   // working order: code of every row, double-buffered for the sort
@@ -1157,6 +1137,8 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         w.centre = (float *)take(sizeof(float) * nb * G * 8);
         w.radius = (float *)take(sizeof(float) * nb);
         w.csq = (float *)take(sizeof(float) * nb);
+        w.Cb = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32) * G * 8);
+        w.nhc = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32 + 64));
         w.act_cnt = (int *)take(sizeof(int) * nb);
         w.act_list = (int *)take(sizeof(int) * (nb / 2 + 1) * nb);   // one row per workgroup of 256 points
         w.hit = (unsigned char *)take((nb / 2 + 1) * nb);
@@ -1288,15 +1270,15 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                        8 * G, (float)eps, w.act_cnt, w.act_list);
     if (p2n_cluster_refines()) {
         P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));
+        const int ntile = (nb128 + 31) / 32;
+        hipLaunchKernelGGL(cl_pack_centres_kernel, dim3((ntile * 32 + 255) / 256), dim3(256), 0, stream, w.centre, w.radius, nb128, ntile * 32,
+                           G, (float)eps, w.Cb, w.nhc);
         if (G == 8)
-            hipLaunchKernelGGL(cl_reach_kernel<1>, dim3(nb128, CL_REACH_SPLIT), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
-                               w.act_cnt, w.act_list, w.reach);
+            hipLaunchKernelGGL(cl_reach_kernel<8>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         else if (G == 16)
-            hipLaunchKernelGGL(cl_reach_kernel<2>, dim3(nb128, CL_REACH_SPLIT), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
-                               w.act_cnt, w.act_list, w.reach);
+            hipLaunchKernelGGL(cl_reach_kernel<16>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         else
-            hipLaunchKernelGGL(cl_reach_kernel<4>, dim3(nb128, CL_REACH_SPLIT), dim3(128), 0, stream, w.Xp, w.nrm, G, w.centre, w.radius, w.csq, nb128, (float)eps,
-                               w.act_cnt, w.act_list, w.reach);
+            hipLaunchKernelGGL(cl_reach_kernel<32>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         hipLaunchKernelGGL(cl_relist_kernel, dim3(nb128 / 2), dim3(256), 0, stream, (const unsigned char *)nullptr, (const int *)nullptr,
                            w.reach, nb128, w.act_cnt, w.act_list);
     }
