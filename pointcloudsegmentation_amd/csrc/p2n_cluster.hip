@@ -129,28 +129,66 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
 // ------------------------------------------------------------------ working order
 // The pair passes prune by blocks of 128 consecutive rows, which only pays when rows that are close in the
 // embedding are close in the index.  A scan may come in any order, so the rows are worked on in the order of a
-// 32-bit code -- the signs of 32 fixed +-1 projections, one bit each: rows of one instance share most bits and
+// 32-bit code -- the signs of 32 fixed +-1 projections about their means, one bit each: rows of one instance share most bits and
 // land in a few runs.  The order changes nothing in the result (neighbourhood sizes, the sets and the border rule
 // are properties of the point set; cluster numbers are re-derived from the caller's indices, cl_rank_kernel),
 // only which blocks ever meet.
-__global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ emb, long N, int D, unsigned *__restrict__ keys,
-                                                      int *__restrict__ vals) {
+// The projections are taken about their MEANS over the scene: embeddings that fill a small part of the sphere are
+// rarely cut by hyperplanes through the origin (nearly every bit would be the same for every row).
+// Step 1: proj[i][k] = (x_i / |x_i|) . r_k, and their sums over the rows (LDS per workgroup, then 32 atomics).
+__global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict__ emb, long N, int D, float *__restrict__ proj,
+                                                         float *__restrict__ psum) {
+    __shared__ float part[4][32];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const float *e = emb + i * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-    for (int d = 0; d < D; ++d) {
-        unsigned hsh = (unsigned)d * 0x9E3779B1u + 0x7F4A7C15u;   // the 32 signs of dimension d
-        hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
-        const float x = e[d];
+    if (i < N) {
+        const float *e = emb + i * D;
+        float ss = 0.f;
+        for (int d = 0; d < D; ++d) {
+            unsigned hsh = (unsigned)d * 0x9E3779B1u + 0x7F4A7C15u;   // the 32 signs of dimension d
+            hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
+            const float x = e[d];
+            ss = fmaf(x, x, ss);
 #pragma unroll
-        for (int k = 0; k < 32; ++k) acc[k] += __uint_as_float(__float_as_uint(x) ^ ((hsh >> k & 1u) << 31));
+            for (int k = 0; k < 32; ++k) acc[k] += __uint_as_float(__float_as_uint(x) ^ ((hsh >> k & 1u) << 31));
+        }
+        const float inv = ss > 0.f ? 1.f / sqrtf(ss) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            acc[k] *= inv;
+            if (!(acc[k] == acc[k])) acc[k] = 0.f;   // a row with a NaN or an infinity: any code will do, but keep it out of the means
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k += 4)
+            *reinterpret_cast<f32x4 *>(proj + i * 32 + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
     }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) atomicAdd(psum + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// Step 2: bit k = projection k above its mean.
+__global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ proj, const float *__restrict__ psum, long N,
+                                                      unsigned *__restrict__ keys, int *__restrict__ vals) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float invn = 1.f / (float)N;
     unsigned key = 0;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) key |= (unsigned)(acc[k] > 0.f) << k;
+    for (int k = 0; k < 32; k += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(proj + i * 32 + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) key |= (unsigned)(v[j] > psum[k + j] * invn) << (k + j);
+    }
     keys[i] = key;
     vals[i] = (int)i;
 }
@@ -1249,7 +1287,12 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
     const int *perm = nullptr;
     if (p2n_cluster_sorts(N)) {   // the working order (cl_code_kernel)
-        hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, D, w.key_a, w.perm);
+        // (the projections borrow Xp, which cl_normalize_kernel fills afterwards: 32 of its >= 64 floats per row; their
+        // sums the first 32 floats of the sort's scratch, which the sort does not touch before cl_code_kernel has run)
+        float *psum = reinterpret_cast<float *>(w.sort_tmp);
+        P2N_CHECK_HIP(hipMemsetAsync(psum, 0, 32 * sizeof(float), stream));
+        hipLaunchKernelGGL(cl_project_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, D, w.Xp, psum);
+        hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, N, w.key_a, w.perm);
         rocprim::double_buffer<unsigned> kb(w.key_a, w.key_b);
         rocprim::double_buffer<int> vb(w.perm, w.val_b);
         size_t tmp = 0;

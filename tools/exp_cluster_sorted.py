@@ -40,21 +40,26 @@ def orders(e, m):
     return p, p2, float(rare.float().mean())
 
 
-n = 166499
-cases = {"33 clusters, random order": torch.from_numpy(make_embeddings(n, 64, 11)).cuda()}
-rng = np.random.default_rng(0)
-pts = (rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64)
-col = rng.integers(0, 256, (n, 3)).astype(np.float64)
-w = dict(np.load(os.path.join(REPO, "tests", "golden", "weights.npz")))
-m_ = Point2Net(feature_dim=6, embedding_dim=64)
-m_.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
-m_ = m_.cuda().eval()
-feat, _, _ = preprocess_point_cloud(torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda())
-with torch.no_grad():
-    cases["model embeddings of a random scene"] = m_(feat)[0].contiguous()
-for name, e in cases.items():
-    for m in (4, 8, 32):
-        p, p2, frac = orders(e, m)
-        t1, _ = timed(lambda: cluster_embeddings(e[p].contiguous()))
-        t2, _ = timed(lambda: cluster_embeddings(e[p2].contiguous()))
-        print(f"{name:38s} code order {t1:6.2f} ms   rare codes (run < {m}, {100*frac:4.1f} % of rows) last {t2:6.2f} ms", flush=True)
+def main():
+    n = 166499
+    cases = {"33 clusters, random order": torch.from_numpy(make_embeddings(n, 64, 11)).cuda()}
+    rng = np.random.default_rng(0)
+    pts = (rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64)
+    col = rng.integers(0, 256, (n, 3)).astype(np.float64)
+    w = dict(np.load(os.path.join(REPO, "tests", "golden", "weights.npz")))
+    m_ = Point2Net(feature_dim=6, embedding_dim=64)
+    m_.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+    m_ = m_.cuda().eval()
+    feat, _, _ = preprocess_point_cloud(torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda())
+    with torch.no_grad():
+        cases["model embeddings of a random scene"] = m_(feat)[0].contiguous()
+    for name, e in cases.items():
+        for m in (4, 8, 32):
+            p, p2, frac = orders(e, m)
+            t1, _ = timed(lambda: cluster_embeddings(e[p].contiguous()))
+            t2, _ = timed(lambda: cluster_embeddings(e[p2].contiguous()))
+            print(f"{name:38s} code order {t1:6.2f} ms   rare codes (run < {m}, {100*frac:4.1f} % of rows) last {t2:6.2f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
