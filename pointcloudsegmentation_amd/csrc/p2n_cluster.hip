@@ -675,49 +675,43 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
 // scene are farther apart than eps and never need their 128 x 128 distance tile.
 #define CL_SPH_MARGIN 1e-4f   // fp32 slack of centre / radius / centre-distance arithmetic (vectors are unit length)
 __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
-                                                        float *__restrict__ centre, float *__restrict__ radius,
-                                                        float *__restrict__ csq) {
-    extern __shared__ float sph[];   // [8G] centre, then reduction scratch
-    float *cen = sph, *red = sph + 8 * G;
-    const int b = blockIdx.x, t = threadIdx.x;
+                                                        float *__restrict__ centre, float *__restrict__ radius) {
+    extern __shared__ float sph[];   // [8G] centre, [2][8G] the two waves' column sums, [4] scalars
+    float *cen = sph, *part = sph + 8 * G, *sc = sph + 3 * 8 * G;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, Dp = 8 * G;
     const long i = (long)b * 128 + t;
     const bool real = nh[i] > -__builtin_inff();
     const float *px = Xp + ((i >> 5) * G * 64 + (i & 31)) * 4;
-    // count of real rows
-    red[t] = real ? 1.f : 0.f;
+    // column sums: a shuffle reduction per column inside each wave (no barrier per column), the two waves' sums through LDS
+    const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
+    if (lane == 0) sc[wave] = (float)__builtin_popcountll(rm);
+    for (int k = 0; k < Dp; ++k) {
+        float v = real ? px[(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (k & 3)] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) part[wave * Dp + k] = v;
+    }
     __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-    const float cntf = red[0];
-    __syncthreads();
+    const float cntf = sc[0] + sc[1];
     if (cntf == 0.f) {
-        if (t == 0) { radius[b] = -1.f; csq[b] = 0.f; }
-        for (int k = t; k < 8 * G; k += 128) centre[(long)b * 8 * G + k] = 0.f;
+        if (t == 0) radius[b] = -1.f;
+        for (int k = t; k < Dp; k += 128) centre[(long)b * Dp + k] = 0.f;
         return;
     }
-    for (int k = 0; k < 8 * G; ++k) {   // column means (D <= 256: at most 256 short reductions)
-        const float v = real ? px[(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (k & 3)] : 0.f;
-        red[t] = v;
-        __syncthreads();
-        for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-        if (t == 0) cen[k] = red[0] / cntf;
-        __syncthreads();
-    }
+    for (int k = t; k < Dp; k += 128) cen[k] = (part[k] + part[Dp + k]) / cntf;
+    __syncthreads();
     float d2 = 0.f;
     if (real)
-        for (int k = 0; k < 8 * G; ++k) {
+        for (int k = 0; k < Dp; ++k) {
             const float d = px[(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (k & 3)] - cen[k];
             d2 = fmaf(d, d, d2);
         }
-    red[t] = d2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o));
+    if (lane == 0) sc[2 + wave] = d2;
     __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
-    if (t == 0) {
-        radius[b] = sqrtf(red[0]) + CL_SPH_MARGIN;
-        float sq = 0.f;   // |centre|^2 for cl_reach_kernel
-        for (int k = 0; k < 8 * G; ++k) sq = fmaf(cen[k], cen[k], sq);
-        csq[b] = sq;
-    }
-    for (int k = t; k < 8 * G; k += 128) centre[(long)b * 8 * G + k] = cen[k];   // (up to 256 dimensions, 128 threads)
+    if (t == 0) radius[b] = sqrtf(fmaxf(sc[2], sc[3])) + CL_SPH_MARGIN;
+    for (int k = t; k < Dp; k += 128) centre[(long)b * Dp + k] = cen[k];   // (up to 256 dimensions, 128 threads)
 }
 
 // grid = row groups of 256 points.  list[ib][0..cnt) = column blocks jb (ascending) that can reach either of the
@@ -1115,7 +1109,7 @@ struct ClWs {
     int *cnt, *parent, *nbr_cnt, *rank, *blk_has_core, *nbr;
     unsigned char *core;
     unsigned long long *stats;
-    float *centre, *radius, *csq;
+    float *centre, *radius;
     float *Cb, *nhc;   // centres in the fragment layout of Xb, and their accumulator start values (cl_pack_centres_kernel)
     int *act_cnt, *act_list;
     unsigned char *hit, *reach;
@@ -1174,7 +1168,6 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
         const size_t nb = (size_t)Npad / 128;
         w.centre = (float *)take(sizeof(float) * nb * G * 8);
         w.radius = (float *)take(sizeof(float) * nb);
-        w.csq = (float *)take(sizeof(float) * nb);
         w.Cb = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32) * G * 8);
         w.nhc = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32 + 64));
         w.act_cnt = (int *)take(sizeof(int) * nb);
@@ -1307,8 +1300,8 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm, w.Xb,
                        perm);
     const int nb128 = (int)(Npad / 128);
-    hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (8 * G + 128), stream, w.Xp, w.nrm, G, w.centre,
-                       w.radius, w.csq);
+    hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (3 * 8 * G + 4), stream, w.Xp, w.nrm, G, w.centre,
+                       w.radius);
     hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
                        8 * G, (float)eps, w.act_cnt, w.act_list);
     if (p2n_cluster_refines()) {
