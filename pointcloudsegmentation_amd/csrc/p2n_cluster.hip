@@ -4,8 +4,8 @@
 // (:131-140).  SURVEY.md section 8f rank 1; oracle/p2n_oracle.c (orc_dbscan) is the CPU
 // restatement this is tested against, itself pinned on scikit-learn's output.
 //
-// DBSCAN is brute force here, as in scikit-learn for D > 15: two passes over all N x N pairs,
-// each a Gram-matrix GEMM on the exact-fp32 MFMA (d2 = |a|^2 + |b|^2 - 2 a.b), never storing
+// DBSCAN is brute force here, as in scikit-learn for D > 15: two passes over the pairs of rows,
+// each a Gram-matrix GEMM on the matrix pipe (d2 = |a|^2 + |b|^2 - 2 a.b), never storing
 // distances or adjacency:
 //   pass 1 (count) neighbourhood sizes -> core flags;
 //   pass 2 (link)  core-core edges -> lock-free union-find whose roots are the LOWEST index of
@@ -14,6 +14,18 @@
 // A pair whose fp32 d2 lies within `tau` of eps^2 is decided by an exact recomputation in
 // double (sum_k ((double)a_k-(double)b_k)^2, k ascending, no fma): the arithmetic of the
 // oracle, so labels are bit-identical to it.
+//
+// Which pairs: 256-row workgroups against blocks of 128 rows, and only the block pairs that can hold
+// a pair within eps.  The stages before pass 1 see to that:
+//   working order   rows sorted by a 32-bit code of their embedding (cl_project/code_kernel, rocPRIM
+//                   sort), so that a block's rows are neighbours in the embedding whatever order
+//                   the caller's scan came in; labels / counts / cluster numbers go back in the
+//                   caller's indices (cl_minorig/owner/rank/label_kernel);
+//   spheres         bounding sphere per block, list of the blocks whose spheres reach (cl_sphere/active);
+//   reach           any point of A within eps of B's sphere AND the other way round (cl_reach_kernel,
+//                   dense on the matrix pipe; cl_relist_kernel);
+//   plan            pass 1's lists cut into chunks of equal length, one workgroup each (cl_plan_kernel);
+//   hits            pass 1 notes per (row block, block) whether any candidate pair showed up: pass 2's lists.
 //
 // Layout: the normalised rows are stored once as MFMA fragments
 //   Xp[tile = point/32][g = k/8][lane = 32*h + point%32][j]  = x[point][8g + 4h + j]
