@@ -318,6 +318,10 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     constexpr int UT = CT >= 2 ? 2 : 1;   // tiles per unit (independent MFMA chains)
     constexpr int UPS = CT / UT;          // units per streamed block
     constexpr int EL = UT * 16;           // pairs per lane per unit
+    // MODE 0: pass 1; MODE 2: pass 1 visiting every block pair once (the Gram tile of (A, B) is the transpose of
+    // (B, A)'s): lists hold only blocks at or after the row block's own, and beyond those a cell counts its definite
+    // pairs for the streamed points too (column counts by ballot, below); MODE 1: pass 2.
+    constexpr bool P1 = MODE != 1, SYM = MODE == 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     // Pass 1 takes chunk blockIdx.x of the work list (the grid is the host's bound on the number of chunks).  Pass 2
@@ -325,8 +329,8 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     // row block then run one after the other rather than side by side, each starting from the parents the last left
     // (side by side, every one of them unites the same rows again: 29 M -> 84 M union attempts, 1.3 -> 3.1 ms).
     const int chunk = blockIdx.x;
-    if (MODE == 0 && chunk >= A.work_meta[0]) return;
-    const int rb = MODE == 0 ? A.work_rb[chunk] : (int)blockIdx.x;   // this workgroup's 256 rows
+    if (P1 && chunk >= A.work_meta[0]) return;
+    const int rb = P1 ? A.work_rb[chunk] : (int)blockIdx.x;   // this workgroup's 256 rows
     const long i0 = ((long)rb * CL_NW + wave) * 32;
     const long my = i0 + c;               // the point this lane owns
 
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     constexpr int SUB = 128 / JB;         // streamed blocks per 128-point block
     const int total = A.act_cnt[rb];
     int e0, e1;
-    if (MODE == 0) {
+    if (P1) {
         e0 = A.work_e0[chunk];
         e1 = e0 + A.work_meta[1] < total ? e0 + A.work_meta[1] : total;
     } else {
@@ -347,12 +351,16 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     int *slist = reinterpret_cast<int *>(lds + CL_LDS_FLOATS);   // this workgroup's slice of the list
     for (int i = threadIdx.x; i < e1 - e0; i += CL_NW * 64) slist[i] = A.act_list[(long)rb * A.nb128 + e0 + i];
     if (MODE == 1 && threadIdx.x < 8) lds[CL_PU_BASE + threadIdx.x] = __int_as_float(-1);   // pass 2, a wave that stages no parents: "no core point"
+    // MODE 2: the three parent slots of pass 2 serve as rotating column counters (block t uses slot t % 3: its last
+    // unit is compared during block t+1's first step, and it is flushed to cnt[] at the entry of block t+2)
+    int *colslots = reinterpret_cast<int *>(lds + CL_PAR_BASE);
+    if (SYM && threadIdx.x < 3 * 128) colslots[threadIdx.x] = 0;
     __syncthreads();
     auto jbof = [&](long pos) -> long { return (long)slist[pos / SUB] * SUB + pos % SUB; };
     // Pass 1: every workgroup walks the blocks in the same order (a block is fetched from HBM once per
     // XCD, then served from its L2).  Pass 2: staggered starts spread the union-find merges instead of
     // piling every workgroup onto one block's roots at the same time.
-    long cur = MODE == 0 ? 0 : ((long)rb * (CL_NW * 32 / JB)) % len;
+    long cur = P1 ? 0 : ((long)rb * (CL_NW * 32 / JB)) % len;
 
     auto stage = [&](long jb, int buf) {
         float *dst = lds + buf * CL_BLK_FLOATS;
@@ -438,9 +446,22 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             acc[ut] = MFMAB(b, term == 1 ? al[ks] : ah[ks], acc[ut]);
         }
     };
-    auto fast_pair = [&](const f32x16(&acc)[UT], int e) __attribute__((always_inline)) {
+    // colv (MODE 2): lane L collects the number of this wave's rows that have column L of the unit definitely inside
+    // -- the compare's lane mask is there anyway; its two halves (the lane halves hold different columns) are counted
+    // on the scalar unit and dropped into the column's lane.
+    auto fast_pair = [&](const f32x16(&acc)[UT], int e, int &colv) __attribute__((always_inline)) {
         const float v = acc[e >> 4][e & 15];
-        if (MODE == 0) cntd += (v >= hd);
+        if (P1) {
+            const bool d = v >= hd;
+            cntd += d;
+            if (SYM) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(d);
+                const int r = e & 15, idx = (e >> 4) * 32 + 8 * (r >> 2) + (r & 3);
+                const int n0 = __builtin_popcount((unsigned)m), n1 = __builtin_popcount((unsigned)(m >> 32));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(colv) : "s"(n0), "n"(idx));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(colv) : "s"(n1), "n"(idx + 4));
+            }
+        }
         cntm += (v >= hm);
     };
     // a finished unit in which some lane saw an undecided pair (pass 1) or any candidate edge (pass 2)
@@ -456,7 +477,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                 for (int q = 0; q < 4; ++q) {
                     const int r = 4 * gq + q, e = ut * 16 + r;
                     const float v = acc[ut][r];
-                    if (MODE == 0) {
+                    if (P1) {
                         need |= (unsigned)(v >= hm && !(v >= hd)) << e;
                     } else {
                         const bool nd = v >= hm && __float_as_int(pjv[q]) != pi;
@@ -516,13 +537,16 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             need &= need - 1;
             const int ut = e >> 4, r = e & 15;
             const long other = col0 + ut * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (MODE == 0) {
+            if (P1) {
+                const bool both = SYM && (col0 >> 7) > 2L * rb + 1;   // the pair counts for the streamed point too
                 if (dq_n < A.defer_cap) {
-                    A.defer_q[(dq_wave * A.defer_cap + dq_n) * 64 + lane] = (int)other;
+                    A.defer_q[(dq_wave * A.defer_cap + dq_n) * 64 + lane] = (int)other | (both ? (int)0x80000000 : 0);
                     ++dq_n;
                 } else {
                     atomicAdd(A.stats + 0, 1ull);
-                    cntd += cl_exact_within(A.Xp, G, my, other, A.eps2);
+                    const bool in = cl_exact_within(A.Xp, G, my, other, A.eps2);
+                    cntd += in;
+                    if (both && in) atomicAdd(A.cnt + other, 1);
                 }
             } else {
                 // the staged parent against the CURRENT own parent: after a call the row usually names the root that
@@ -550,6 +574,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     // one pipeline stage: GEMM of unit w into `accn` while unit w-1 (in `accp`) is compared
     const long W = len * UPS;
     long col0_prev = 0, jb_cur = 0;
+    long cb1 = 0, cb2 = 0;   // MODE 2: first column of the blocks one and two steps back
     bool prev_active = false, blk_active = false;
     const float *par_prev = lds;
     int u_prev = 0;
@@ -576,6 +601,18 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                 }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                if (SYM) {   // every wave has dropped its last counts for block t-2: out they go (zeros stay for block t+1)
+                    if (t >= 2 && threadIdx.x < JB) {
+                        int *sl = colslots + (int)((t + 1) % 3) * 128;
+                        const int cv = sl[threadIdx.x];
+                        if (cv) {
+                            atomicAdd(A.cnt + cb2 + threadIdx.x, cv);
+                            sl[threadIdx.x] = 0;
+                        }
+                    }
+                    cb2 = cb1;
+                    cb1 = jb_cur * JB;
+                }
                 if (MODE == 1) {   // own parent, one block stale: the filter below only needs SOME past ancestor of `my`
                     pi = pi_nxt;
                     pi_nxt = CL_LD(A.parent + my);
@@ -585,7 +622,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                 cur = nxt;
                 jb_now = jb_nxt;
                 jb_nxt = jb_after;
-                blk_active = MODE == 0 || A.colblk_has_core[(jb_cur * JB) >> 7] != 0;
+                blk_active = P1 || A.colblk_has_core[(jb_cur * JB) >> 7] != 0;
                 if (MODE == 1) {
                     // A cell whose columns all name one parent that every row of this wave names too joins nothing
                     // (both values are past ancestors, and sets only grow): the wave sits the block out.  Rows that
@@ -602,13 +639,14 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         const float *ubuf = blk + u * UT * G * 256;
         const long col0 = jb_cur * JB + u * UT * 32;
         const int before = cntm;
+        int colv = 0;
         if (active && prev_active) {   // the steady state: one straight-line block, compares between the MFMAs
             init_acc(accn, blk, u);
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) {
                 mfma_slot(accn, ubuf, sl);
 #pragma unroll
-                for (int e = sl * EL / NSL; e < (sl + 1) * EL / NSL; ++e) fast_pair(accp, e);
+                for (int e = sl * EL / NSL; e < (sl + 1) * EL / NSL; ++e) fast_pair(accp, e, colv);
             }
         } else {
             if (active) {
@@ -618,7 +656,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             }
             if (prev_active) {
 #pragma unroll
-                for (int e = 0; e < EL; ++e) fast_pair(accp, e);
+                for (int e = 0; e < EL; ++e) fast_pair(accp, e, colv);
             }
         }
         if (u == 0 && pfetch && w < W && t + 1 < len)   // parents of the next block -> its LDS buffer (read after the next barrier)
@@ -627,12 +665,14 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             const int cp = common_parent(pnext);
             if (lane == 0) lds[CL_PU_BASE + (int)((t + 1) % 3) * 2 + wave - 2] = __int_as_float(cp);
         }
+        if (SYM && prev_active && (col0_prev >> 7) > 2L * rb + 1 && lane < UT * 32)   // (the row block's own two blocks are visited both ways round)
+            atomicAdd(reinterpret_cast<int *>(const_cast<float *>(par_prev)) + u_prev * UT * 32 + lane, colv);
         if (prev_active) {
             // Pass 1 notes which streamed blocks held any candidate pair at all for this row block: pass 2 tests the
             // same accumulator values against the same threshold, so it can leave every other block out
             // (cl_relist_kernel).  Several waves may write the same byte; they all write 1.  An undecided pair is
             // a candidate pair, so the common case of a unit without any costs one vote.
-            if (MODE == 0) {
+            if (P1) {
                 if (__builtin_amdgcn_ballot_w64(cntm != before)) {
                     if (lane == 0) A.hit[(long)rb * A.nb128 + (col0_prev >> 7)] = 1;
                     if (__builtin_amdgcn_ballot_w64(cntm - cntd != expdiff)) {
@@ -668,7 +708,18 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             if (st_border) atomicAdd(A.stats + 3, (unsigned long long)st_border);
         }
     }
-    if (MODE == 0) {
+    if (SYM) {   // the column counts of the last two blocks
+        __syncthreads();
+        if (threadIdx.x < JB) {
+            const int c1 = colslots[(int)((len - 1) % 3) * 128 + threadIdx.x];
+            if (c1) atomicAdd(A.cnt + cb1 + threadIdx.x, c1);
+            if (len >= 2) {
+                const int c2 = colslots[(int)((len - 2) % 3) * 128 + threadIdx.x];
+                if (c2) atomicAdd(A.cnt + cb2 + threadIdx.x, c2);
+            }
+        }
+    }
+    if (P1) {
         A.defer_cnt[dq_wave * 64 + lane] = dq_n;
         {
             int qs = dq_n;   // queued tests of this wave -> stats[0]
@@ -855,12 +906,17 @@ __global__ __launch_bounds__(256) void cl_reach_kernel(const float *__restrict__
 // before its own, and a chunk of 256 entries is read (barriers of the scan) before any of it is written.
 // With `reach` (before pass 1) the rule is the point-to-sphere test of cl_reach_kernel instead, both ways round.
 __global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__restrict__ hit, const int *__restrict__ blk_has_core,
-                                                        const unsigned char *__restrict__ reach, int nb,
+                                                        const unsigned char *__restrict__ reach, int nb, int sym,
                                                         int *__restrict__ act_cnt, int *__restrict__ act_list) {
     __shared__ int scan[256];
     __shared__ int base;
     const int ib = blockIdx.x, t = threadIdx.x;
-    const int total = act_cnt[ib];
+    // sym (pass 1 visits every block pair once, MODE 2 of the pair kernel): before pass 1 the list keeps only blocks
+    // at or after the row block's own; after it pass 1's list is that half, so every block is a candidate again, and
+    // for the blocks before its own the row block finds its hits filed under the OTHER side (the workgroup that held
+    // block jb as rows against this row block's two blocks as columns: a superset at that side's 256-row granularity).
+    const bool all = sym && !reach;
+    const int total = all ? nb : act_cnt[ib];
     int *list = act_list + (long)ib * nb;
     if (t == 0) base = 0;
     __syncthreads();
@@ -868,12 +924,15 @@ __global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__r
         const int e = e0 + t;
         int jb = 0, keep = 0;
         if (e < total) {
-            jb = list[e];
+            jb = all ? e : list[e];
             if (reach) {
                 const long a0 = 2L * ib, a1 = a0 + 1;
                 keep = (reach[a0 * nb + jb] && reach[(long)jb * nb + a0]) || (reach[a1 * nb + jb] && reach[(long)jb * nb + a1]);
+                if (sym && jb < 2 * ib) keep = 0;
             } else {
-                keep = hit[(long)ib * nb + jb] != 0 && blk_has_core[jb] != 0;
+                const bool h = (!sym || jb >= 2 * ib) ? hit[(long)ib * nb + jb] != 0
+                                                      : (hit[(long)(jb >> 1) * nb + 2 * ib] | hit[(long)(jb >> 1) * nb + 2 * ib + 1]) != 0;
+                keep = h && blk_has_core[jb] != 0;
             }
         }
         scan[t] = keep;
@@ -974,8 +1033,13 @@ __global__ __launch_bounds__(256) void cl_resolve_kernel(const float *__restrict
     if (s0 >= n) return;
     const long my = ((long)work_rb[wave / CL_NW] * CL_NW + wave % CL_NW) * 32 + (lane & 31);   // wave / CL_NW: the pair pass's chunk
     int add = 0;   // (the tests are counted in stats[0] by the pair pass: one atomic per wave there)
-    for (int s = s0; s < n && s < s0 + CL_RESOLVE_SG; ++s)
-        add += cl_exact_within(Xp, G, my, q[(wave * cap + s) * 64 + lane], eps2);
+    for (int s = s0; s < n && s < s0 + CL_RESOLVE_SG; ++s) {
+        const int qv = q[(wave * cap + s) * 64 + lane];   // sign bit: the pair counts for the other point too (MODE 2 of the pair pass)
+        const long other = qv & 0x7fffffff;
+        const bool in = cl_exact_within(Xp, G, my, other, eps2);
+        add += in;
+        if (in && qv < 0) atomicAdd(cnt + other, 1);
+    }
     if (add) atomicAdd(cnt + my, add);
 }
 
@@ -1246,6 +1310,11 @@ static bool p2n_cluster_sorts(long N) {
     return N > 256 && !(e && atoi(e) == 0);
 }
 
+static bool p2n_cluster_symmetric() {
+    const char *e = getenv("P2N_CL_SYM");
+    return !(e && atoi(e) == 0);
+}
+
 static bool p2n_cluster_refines() {
     const char *e = getenv("P2N_CL_REACH");
     return !(e && atoi(e) == 0);
@@ -1259,8 +1328,12 @@ static int cl_launch_pairs(int mode, const ClArgs &a, int kbound, hipStream_t st
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_pair_kernel<G, CT, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     if (mode == 0)
         hipLaunchKernelGGL((cl_pair_kernel<G, CT, 0>), dim3((unsigned)kbound), dim3(CL_NW * 64), ldsb, stream, a);
+    else if (mode == 2)
+        hipLaunchKernelGGL((cl_pair_kernel<G, CT, 2>), dim3((unsigned)kbound), dim3(CL_NW * 64), ldsb, stream, a);
     else
         hipLaunchKernelGGL((cl_pair_kernel<G, CT, 1>), dim3((unsigned)kbound, a.nsplit), dim3(CL_NW * 64), ldsb, stream, a);
     P2N_CHECK_HIP(hipGetLastError());
@@ -1316,6 +1389,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                        w.radius);
     hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
                        8 * G, (float)eps, w.act_cnt, w.act_list);
+    const int sym = p2n_cluster_refines() && p2n_cluster_symmetric();   // (the halved lists are made by the reach stage's relist)
     if (p2n_cluster_refines()) {
         P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));
         const int ntile = (nb128 + 31) / 32;
@@ -1328,7 +1402,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         else
             hipLaunchKernelGGL(cl_reach_kernel<32>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         hipLaunchKernelGGL(cl_relist_kernel, dim3(nb128 / 2), dim3(256), 0, stream, (const unsigned char *)nullptr, (const int *)nullptr,
-                           w.reach, nb128, w.act_cnt, w.act_list);
+                           w.reach, nb128, sym, w.act_cnt, w.act_list);
     }
     P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
     P2N_CHECK_HIP(hipMemsetAsync(w.defer_cnt, 0, sizeof(int) * (size_t)w.defer_waves * 64, stream));   // workgroups without work write nothing
@@ -1352,9 +1426,9 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
 
     ps = p2n_prof_begin(P2N_K_CLUSTER_COUNT, stream);
     hipLaunchKernelGGL(cl_plan_kernel, dim3(1), dim3(1024), 0, stream, w.act_cnt, (int)nrowblk, w.kslots, w.work_rb, w.work_e0, w.work_meta);
-    if (G == 8) rc = cl_launch_pairs<8, 4>(0, a, w.kbound, stream);
-    else if (G == 16) rc = cl_launch_pairs<16, 2>(0, a, w.kbound, stream);
-    else rc = cl_launch_pairs<32, 1>(0, a, w.kbound, stream);
+    if (G == 8) rc = cl_launch_pairs<8, 4>(sym ? 2 : 0, a, w.kbound, stream);
+    else if (G == 16) rc = cl_launch_pairs<16, 2>(sym ? 2 : 0, a, w.kbound, stream);
+    else rc = cl_launch_pairs<32, 1>(sym ? 2 : 0, a, w.kbound, stream);
     p2n_prof_end(ps, stream);
     if (rc) return rc;
 
@@ -1369,7 +1443,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                        w.nrm_core, w.parent, w.nbr_cnt, w.blk_has_core);
     a.nrm_col = w.nrm_core;
     ps = p2n_prof_begin(P2N_K_CLUSTER_LINK, stream);
-    hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, (const unsigned char *)nullptr, nb128, w.act_cnt,
+    hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, (const unsigned char *)nullptr, nb128, sym, w.act_cnt,
                        w.act_list);
     a.nsplit = cl_nsplit(Npad);
     if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, (int)nrowblk, stream);

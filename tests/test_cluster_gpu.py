@@ -149,3 +149,23 @@ def test_shuffled_rows_get_the_same_partition_numbered_by_first_index():
     idx = torch.arange(N, device=e.device)
     first.scatter_reduce_(0, lab2[core2], idx[core2], reduce="amin")
     assert bool((first[1:-1] < first[2:]).all())
+
+
+@pytest.mark.parametrize("env", [{"P2N_CL_SYM": "0"}, {"P2N_CL_REACH": "0"}, {"P2N_CL_SYM": "0", "P2N_CL_SORT": "0"}])
+@pytest.mark.parametrize("N,D,k,ms,eps,order", [(12000, 64, 20, 40, 0.1, "random"), (6000, 200, 6, 20, 0.12, "runs"),
+                                                (7000, 128, 8, 25, 0.1, "random")])
+def test_pruning_stages_switched_off_change_nothing(monkeypatch, env, N, D, k, ms, eps, order):
+    """The stages that decide WHICH block pairs the passes visit -- every pair once with counts for both
+    sides (P2N_CL_SYM), the point-to-sphere test (P2N_CL_REACH), the working order -- can be switched off
+    one by one; counts and labels must stay the oracle's (the default, all on, is what every other test
+    of this file runs)."""
+    from oracle import oracle
+    from pointcloudsegmentation_amd.clustering import cluster_embeddings
+    from pointcloudsegmentation_amd.synth import make_embeddings
+    for name, val in env.items():
+        monkeypatch.setenv(name, val)
+    e = make_embeddings(N, D, N + D + 2, n_clusters=k, order=order)
+    want, wcnt = oracle.dbscan(oracle.normalize_rows(e), eps, ms, return_counts=True)
+    got, cnt = cluster_embeddings(torch.from_numpy(e).cuda(), eps, ms, return_counts=True)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
+    np.testing.assert_array_equal(got.cpu().numpy(), want.astype(np.int64))
