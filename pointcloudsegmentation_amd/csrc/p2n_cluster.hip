@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
 // embedding are close in the index.  A scan may come in any order, so the rows are worked on in the order of a
 // 32-bit code -- the signs of 32 fixed +-1 projections about their means, one bit each: rows of one instance share most bits and
 // land in a few runs.  The order changes nothing in the result (neighbourhood sizes, the sets and the border rule
-// are properties of the point set; cluster numbers are re-derived from the caller's indices, cl_rank_kernel),
+// are properties of the point set; cluster numbers are re-derived from the caller's indices, cl_rank_assign_kernel),
 // only which blocks ever meet.
 // The projections are taken about their MEANS over the scene: embeddings that fill a small part of the sphere are
 // rarely cut by hyperplanes through the origin (nearly every bit would be the same for every row).
@@ -1067,62 +1067,78 @@ __global__ __launch_bounds__(256) void cl_flatten_kernel(int *__restrict__ paren
     if (r != (int)i) CL_ST(parent + i, r);   // a non-root's parent: only ever shortened
 }
 
-// roots -> consecutive cluster numbers 1.. in ascending root order (single workgroup scan)
+// roots -> consecutive cluster numbers 1.. in ascending root order.  Two launches over chunks of 8,192 indices:
+// cl_rank_count_kernel counts each chunk's roots, cl_rank_assign_kernel sums the counts of the chunks before its own
+// (a few dozen values) and numbers its roots; a single workgroup walking all N took 97 us at 166,499 points.
 // With a working order (owner != null) the scan runs over the CALLER's indices: owner[o] = root of the set whose
 // lowest caller index among core points is o (-1 elsewhere), so sets are numbered as if the rows had never moved.
-__global__ __launch_bounds__(1024) void cl_rank_kernel(int *__restrict__ parent, const unsigned char *__restrict__ core, long N,
-                                                       int *__restrict__ rank, int *__restrict__ num_clusters,
-                                                       const int *__restrict__ owner) {
+// Without one, parent[] has been flattened (cl_flatten_kernel) and a root is a core point that names itself.
+#define CL_RANK_PT 8   // consecutive indices per thread, 1,024 threads per chunk
+__device__ __forceinline__ int cl_rank_slot(const int *parent, const unsigned char *core, const int *owner, long N, long i) {
+    if (i >= N) return -1;
+    if (owner) return owner[i];
+    return core[i] && parent[i] == (int)i ? (int)i : -1;
+}
+__global__ __launch_bounds__(1024) void cl_rank_count_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
+                                                             const int *__restrict__ owner, long N, int *__restrict__ chunk_cnt) {
     __shared__ int wsum[16];
-    __shared__ int base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base = 0;
+    const long i0 = ((long)blockIdx.x * 1024 + threadIdx.x) * CL_RANK_PT;
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < CL_RANK_PT; ++j) n += cl_rank_slot(parent, core, owner, N, i0 + j) >= 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
     __syncthreads();
-    constexpr int PT = 8;   // consecutive indices per thread: a single workgroup walks N in N / 8192 steps
-    for (long s = 0; s < N; s += 1024 * PT) {
-        const long i0 = s + (long)threadIdx.x * PT;
-        int slot[PT];
-        unsigned rootm = 0;
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        chunk_cnt[blockIdx.x] = tot;
+    }
+}
+__global__ __launch_bounds__(1024) void cl_rank_assign_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
+                                                              const int *__restrict__ owner, long N,
+                                                              const int *__restrict__ chunk_cnt, int *__restrict__ rank,
+                                                              int *__restrict__ num_clusters) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // roots in the chunks before this one (every workgroup sums them itself: at most N / 8192 values)
+        int b = 0;
+        for (int c = threadIdx.x; c < (int)blockIdx.x; c += 1024) b += chunk_cnt[c];
 #pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const long i = i0 + j;
-            slot[j] = (int)i;
-            bool root = false;
-            if (owner) {
-                if (i < N) {
-                    slot[j] = owner[i];
-                    root = slot[j] >= 0;
-                }
-            } else if (i < N && core[i]) {
-                const int r = cl_find(parent, (int)i);
-                parent[i] = r;                       // flattened: every core point names its root
-                root = (r == (int)i);
-            }
-            rootm |= (unsigned)root << j;
-        }
-        const int mine = __builtin_popcount(rootm);
-        int incl = mine;                             // inclusive scan over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int off = base + incl - mine;
-        for (int w = 0; w < wave; ++w) off += wsum[w];
-#pragma unroll
-        for (int j = 0; j < PT; ++j)
-            if (rootm >> j & 1) rank[slot[j]] = ++off;
+        for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o);
+        if (lane == 0) wsum[wave] = b;
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0;
             for (int w = 0; w < 16; ++w) tot += wsum[w];
-            base += tot;
+            base_s = tot;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && num_clusters) *num_clusters = base;
+    const long i0 = ((long)blockIdx.x * 1024 + threadIdx.x) * CL_RANK_PT;
+    int slot[CL_RANK_PT], mine = 0;
+#pragma unroll
+    for (int j = 0; j < CL_RANK_PT; ++j) {
+        slot[j] = cl_rank_slot(parent, core, owner, N, i0 + j);
+        mine += slot[j] >= 0;
+    }
+    int incl = mine;                             // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    __syncthreads();                             // (wsum is reused)
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = base_s + incl - mine;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+    for (int j = 0; j < CL_RANK_PT; ++j)
+        if (slot[j] >= 0) rank[slot[j]] = ++off;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023 && num_clusters) *num_clusters = off;   // the last thread of the last chunk ends on the total
 }
 
 __global__ __launch_bounds__(256) void cl_label_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
@@ -1191,7 +1207,7 @@ struct ClWs {
     unsigned char *hit, *reach;
     unsigned *key_a, *key_b;   // working order: code of every row, double-buffered for the sort
     int *perm, *val_b;         // working row -> caller's index (the sort's values)
-    int *minorig, *owner;
+    int *minorig, *owner, *chunk_cnt;
     void *sort_tmp;
     size_t sort_tmp_bytes;
     int *defer_q, *defer_cnt;
@@ -1258,6 +1274,7 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
     w.val_b = (int *)take(sizeof(int) * Npad);
     w.minorig = (int *)take(sizeof(int) * Npad);
     w.owner = (int *)take(sizeof(int) * Npad);
+    w.chunk_cnt = (int *)take(sizeof(int) * (Npad / (1024 * CL_RANK_PT) + 2));
     w.sort_tmp_bytes = (size_t)Npad * 8 + (4u << 20);   // the double-buffered radix sort needs its digit counts only; checked at the call
     w.sort_tmp = take(w.sort_tmp_bytes);
     cl_chunks(Npad, w.kslots, w.kbound);
@@ -1461,8 +1478,15 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         hipLaunchKernelGGL(cl_minorig_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, perm, N, w.minorig);
         hipLaunchKernelGGL(cl_owner_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, N, w.minorig, w.owner);
     }
-    hipLaunchKernelGGL(cl_rank_kernel, dim3(1), dim3(1024), 0, stream, w.parent, w.core, N, w.rank, num_clusters,
-                       perm ? w.owner : (const int *)nullptr);
+    else   // (the numbering reads parent[] flat either way)
+        hipLaunchKernelGGL(cl_flatten_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.parent, w.core, N);
+    {
+        const int *owner = perm ? w.owner : (const int *)nullptr;
+        const unsigned nchunk = (unsigned)((N + 1024 * CL_RANK_PT - 1) / (1024 * CL_RANK_PT));
+        hipLaunchKernelGGL(cl_rank_count_kernel, dim3(nchunk), dim3(1024), 0, stream, w.parent, w.core, owner, N, w.chunk_cnt);
+        hipLaunchKernelGGL(cl_rank_assign_kernel, dim3(nchunk), dim3(1024), 0, stream, w.parent, w.core, owner, N, w.chunk_cnt, w.rank,
+                           num_clusters);
+    }
     hipLaunchKernelGGL(cl_label_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.parent, w.core, w.rank,
                        w.nbr_cnt, w.nbr, cap, N, labels, perm);
     p2n_prof_end(ps, stream);
