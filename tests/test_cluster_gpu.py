@@ -169,3 +169,33 @@ def test_pruning_stages_switched_off_change_nothing(monkeypatch, env, N, D, k, m
     got, cnt = cluster_embeddings(torch.from_numpy(e).cuda(), eps, ms, return_counts=True)
     np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
     np.testing.assert_array_equal(got.cpu().numpy(), want.astype(np.int64))
+
+
+@pytest.mark.parametrize("env", [{}, {"P2N_CL_SYM": "0"}, {"P2N_CL_SORT": "0"}])
+def test_many_undecided_pairs_per_row_overflow_the_queue(monkeypatch, env):
+    """Two tight groups of 520 points whose every cross pair sits within ~1e-7 of eps: each row has hundreds of
+    pairs the fp32 estimate cannot decide -- far more than the 16 queue slots of a lane, so the pair pass
+    decides most of them on the spot in float64, for the row and (where a block pair is visited once) for the
+    other point too.  Neighbourhood sizes and labels must be the oracle's; min_samples is set so that core
+    status hangs on those decisions."""
+    from oracle import oracle
+    from pointcloudsegmentation_amd.clustering import cluster_embeddings, last_cluster_stats
+    for name, val in env.items():
+        monkeypatch.setenv(name, val)
+    rng = np.random.default_rng(17)
+    n, eps = 520, 0.1
+    e = np.zeros((2 * n + 200, 64), np.float64)
+    e[:n, 0] = 1.0                                          # group A: one direction (+ jitter far below the band)
+    e[:n, 2:6] = rng.standard_normal((n, 4)) * 1e-9
+    th = 2 * np.arcsin(eps * (1 + rng.uniform(-1e-7, 1e-7, n)) / 2)   # group B: chords of eps (1 +- 1e-7) from A
+    e[n:2 * n, 0], e[n:2 * n, 1] = np.cos(th), np.sin(th)
+    e[2 * n:] = rng.standard_normal((200, 64))              # outliers
+    e = np.ascontiguousarray((e * rng.uniform(0.5, 2.0, (len(e), 1))).astype(np.float32))
+    e = e[rng.permutation(len(e))]
+    ms = n + n // 2                                         # a group alone is not enough, the exact cross pairs decide
+    want, wcnt = oracle.dbscan(oracle.normalize_rows(e), eps, ms, return_counts=True)
+    got, cnt = cluster_embeddings(e, eps, ms, return_counts=True)
+    np.testing.assert_array_equal(cnt, wcnt)
+    np.testing.assert_array_equal(got, want.astype(np.int64))
+    assert last_cluster_stats(len(e), 64, ms)["exact_pass1"] > 16 * 64 * 8      # more than the queues of a workgroup hold
+    assert 0 < int((wcnt >= ms).sum()) < 2 * n                                  # some rows core, some not: the decisions mattered
