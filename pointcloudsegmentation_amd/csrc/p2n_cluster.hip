@@ -159,13 +159,21 @@ __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict
     if (i < N) {
         const float *e = emb + i * D;
         float ss = 0.f;
-        for (int d = 0; d < D; ++d) {
+        auto dim = [&](int d, float x) __attribute__((always_inline)) {
             unsigned hsh = (unsigned)d * 0x9E3779B1u + 0x7F4A7C15u;   // the 32 signs of dimension d
             hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
-            const float x = e[d];
             ss = fmaf(x, x, ss);
 #pragma unroll
             for (int k = 0; k < 32; ++k) acc[k] += __uint_as_float(__float_as_uint(x) ^ ((hsh >> k & 1u) << 31));
+        };
+        if ((D & 3) == 0 && (reinterpret_cast<size_t>(emb) & 15) == 0) {   // rows of whole 16-byte pieces: a quarter of the loads
+            for (int d = 0; d < D; d += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(e + d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dim(d + j, v[j]);
+            }
+        } else {
+            for (int d = 0; d < D; ++d) dim(d, e[d]);
         }
         const float inv = ss > 0.f ? 1.f / sqrtf(ss) : 0.f;
 #pragma unroll
@@ -875,6 +883,8 @@ __global__ __launch_bounds__(256) void cl_reach_kernel(const float *__restrict__
         al[ks] = *reinterpret_cast<const cl_bf16x8 *>(Xb + ((i0 >> 5) * G + 2 * ks + 1) * 256 + lane * 4);
     }
     const float hx = -nh[i0 + (lane & 31)] - CL_REACH_SLACK;   // |x|^2 / 2 - slack (+inf on pad rows: reaches nothing)
+    // (fetching a tile's centre fragments one tile ahead was tried: 139 -> 183 us, the other waves of the SIMD hide the
+    // loads better than the extra registers allow)
     for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y) {
         f32x16 acc;
 #pragma unroll
