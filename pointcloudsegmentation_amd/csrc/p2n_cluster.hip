@@ -497,10 +497,36 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         if (MODE == 1 && __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(need) >= CL_DENSE_BITS)) >= 16) {
             // A dense unit: the wave's rows and the unit's columns are one instance's.  Lane by lane every row
             // would unite with every column -- chains of dependent coherent loads, nearly all of them redundant.
-            // Instead, column by column (the same column for all lanes of a lane half at bit e), one core lane whose
-            // edge is certain without a float64 test leads and unites with the column; every core lane that names
-            // the same parent as the leader is in the leader's set already and leaves both the call and the exact
-            // test out.  The lead rotates with e, so the calls that remain run side by side in different lanes.
+            // Every call is several memory round trips and a wave makes its calls in lockstep, so what counts is
+            // the number of ROUNDS of calls, not the number of calls:
+            //  1. hub (only while the rows still name different parents): each lane half takes the first column
+            //     its first certain lane is certain of; every core lane certain of it too unites with it (one
+            //     round, mostly each lane hooking its own root), then looks its root up again (one more round):
+            //     now the rows name one root;
+            //  2. without touching memory: column by column (the same column for all lanes of a lane half at bit
+            //     e) one core lane whose edge is certain leads -- the lead rotates with e -- and every core lane
+            //     that names the leader's parent is in the leader's set already and strikes the column;
+            //  3. each lane works through what is left to it: about one column per lane, all lanes side by side.
+            {
+                const unsigned long long cm = __builtin_amdgcn_ballot_w64(mycore);
+                const int p0 = cm ? __builtin_amdgcn_readlane(pi, __builtin_ctzll(cm)) : 0;
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(mycore && pi != p0)) >= CL_DENSE_BITS) {
+                    const unsigned long long sm = __builtin_amdgcn_ballot_w64(mycore && sure != 0u);
+                    const unsigned slo = (unsigned)sm, shi = (unsigned)(sm >> 32);
+                    int hub0 = -1, hub1 = -1;
+                    if (slo) hub0 = __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)sure, __builtin_ctz(slo)));
+                    if (shi) hub1 = __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)sure, 32 + __builtin_ctz(shi)));
+                    const int hub = h ? hub1 : hub0;
+                    if (hub >= 0 && mycore && (sure >> hub & 1)) {
+                        const int ut = hub >> 4, r = hub & 15;
+                        pi = cl_unite(A.parent, (int)my, (int)(col0 + ut * 32 + 8 * (r >> 2) + 4 * h + (r & 3)));
+                        ++st_union;
+                        need &= ~(1u << hub);
+                    }
+                    if (mycore) pi = cl_find(A.parent, pi);
+                }
+            }
+            unsigned todo = 0u;
 #pragma nounroll
             for (int e = 0; e < EL; ++e) {
                 const bool mine = need >> e & 1;
@@ -518,11 +544,15 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                     q1 = __builtin_amdgcn_readlane(pi, l1);
                 }
                 const int lead = h ? l1 : l0;
-                if (!mine || (mycore && lead >= 0 && lane != lead && pi == (h ? q1 : q0))) continue;
+                if (mine && !(mycore && lead >= 0 && lane != lead && pi == (h ? q1 : q0))) todo |= 1u << e;
+            }
+            while (todo) {
+                const int e = __builtin_ctz(todo);
+                todo &= todo - 1;
                 const int ut = e >> 4, r = e & 15;
                 const long other = col0 + ut * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                 if (mycore && __float_as_int(par[(u * UT + ut) * 32 + 8 * (r >> 2) + 4 * h + (r & 3)]) == pi) continue;
-                bool ok = certain;
+                bool ok = sure >> e & 1;
                 if (!ok) {
                     ok = cl_exact_within(A.Xp, G, my, other, A.eps2);
                     ++st_exact;
