@@ -196,9 +196,46 @@ __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict
     if (threadIdx.x < 32) atomicAdd(psum + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-// Step 2: bit k = projection k above its mean.
-__global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ proj, const float *__restrict__ psum, long N,
-                                                      unsigned *__restrict__ keys, int *__restrict__ vals) {
+// Step 2: how many rows sit within `delta` (= eps) of each projection's mean.  A hyperplane that passes through an
+// instance cuts it into two runs -- far apart in the order if the bit is a significant one, neighbours if it is not.
+// So the projections that cut through the least mass become the most significant bits (step 3); with the bits in
+// fixed order the count and link passes took 10-25 % longer, depending on the luck of the sign matrix
+// (tools/exp_cluster_presorted.py).
+__global__ __launch_bounds__(256) void cl_near_kernel(const float *__restrict__ proj, const float *__restrict__ psum, long N,
+                                                      float delta, int *__restrict__ near) {
+    __shared__ int part[4][32];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invn = 1.f / (float)N;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < N) v = *reinterpret_cast<const f32x4 *>(proj + i * 32 + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(i < N && fabsf(v[j] - psum[k + j] * invn) < delta);
+            if (lane == 0) part[wave][k + j] = (int)__builtin_popcountll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) atomicAdd(near + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// Step 3: bit = projection above its mean, at position 31 - (rank of the projection by mass near its mean, ascending).
+__global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ proj, const float *__restrict__ psum,
+                                                      const int *__restrict__ near, long N, unsigned *__restrict__ keys,
+                                                      int *__restrict__ vals) {
+    __shared__ int pos[32];
+    if (threadIdx.x < 32) {
+        const int mine = near[threadIdx.x];
+        int rank = 0;
+        for (int j = 0; j < 32; ++j) {
+            const int o = near[j];
+            rank += (o < mine) || (o == mine && j < (int)threadIdx.x);
+        }
+        pos[threadIdx.x] = 31 - rank;
+    }
+    __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float invn = 1.f / (float)N;
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ 
     for (int k = 0; k < 32; k += 4) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(proj + i * 32 + k);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) key |= (unsigned)(v[j] > psum[k + j] * invn) << (k + j);
+        for (int j = 0; j < 4; ++j) key |= (unsigned)(v[j] > psum[k + j] * invn) << pos[k + j];
     }
     keys[i] = key;
     vals[i] = (int)i;
@@ -1423,11 +1460,13 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const int *perm = nullptr;
     if (p2n_cluster_sorts(N)) {   // the working order (cl_code_kernel)
         // (the projections borrow Xp, which cl_normalize_kernel fills afterwards: 32 of its >= 64 floats per row; their
-        // sums the first 32 floats of the sort's scratch, which the sort does not touch before cl_code_kernel has run)
+        // sums and near-threshold counts the first 64 words of the sort's scratch, which the sort does not touch before cl_code_kernel has run)
         float *psum = reinterpret_cast<float *>(w.sort_tmp);
-        P2N_CHECK_HIP(hipMemsetAsync(psum, 0, 32 * sizeof(float), stream));
+        int *near = reinterpret_cast<int *>(psum + 32);
+        P2N_CHECK_HIP(hipMemsetAsync(psum, 0, 64 * sizeof(float), stream));
         hipLaunchKernelGGL(cl_project_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, D, w.Xp, psum);
-        hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, N, w.key_a, w.perm);
+        hipLaunchKernelGGL(cl_near_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, N, (float)eps, near);
+        hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, near, N, w.key_a, w.perm);
         rocprim::double_buffer<unsigned> kb(w.key_a, w.key_b);
         rocprim::double_buffer<int> vb(w.perm, w.val_b);
         size_t tmp = 0;

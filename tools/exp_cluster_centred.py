@@ -32,25 +32,30 @@ def order(e, centred, bits=32, seed=5):
     return torch.sort(key, stable=True).indices
 
 
-n = 166499
-cases = {"33 clusters": torch.from_numpy(make_embeddings(n, 64, 11)).cuda()}
-rng = np.random.default_rng(0)
-pts = (rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64)
-col = rng.integers(0, 256, (n, 3)).astype(np.float64)
-w = dict(np.load(os.path.join(REPO, "tests", "golden", "weights.npz")))
-m_ = Point2Net(feature_dim=6, embedding_dim=64)
-m_.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
-m_ = m_.cuda().eval()
-feat, _, _ = preprocess_point_cloud(torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda())
-with torch.no_grad():
-    cases["model embeddings"] = m_(feat)[0].contiguous()
-for name, e in cases.items():
-    for centred in (False, True):
-        p = order(e, centred)
-        es = e[p].contiguous()
-        t, lab = timed(lambda: cluster_embeddings(es))
-        x = normalize_rows(es)
-        nb = n // 128
-        xb = x[:nb * 128].view(nb, 128, 64)
-        rad = (xb - xb.mean(1, keepdim=True)).norm(dim=2).max(1).values
-        print(f"{name:18s} centred {centred!s:5s}  {t:6.2f} ms   block radius median {float(rad.median()):.3f}  clusters {int(lab.max())}", flush=True)
+def main():
+    n = 166499
+    cases = {"33 clusters": torch.from_numpy(make_embeddings(n, 64, 11)).cuda()}
+    rng = np.random.default_rng(0)
+    pts = (rng.uniform(0, 1, (n, 3)) * np.array([8.0, 6.0, 3.0])).astype(np.float32).astype(np.float64)
+    col = rng.integers(0, 256, (n, 3)).astype(np.float64)
+    w = dict(np.load(os.path.join(REPO, "tests", "golden", "weights.npz")))
+    m_ = Point2Net(feature_dim=6, embedding_dim=64)
+    m_.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+    m_ = m_.cuda().eval()
+    feat, _, _ = preprocess_point_cloud(torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda())
+    with torch.no_grad():
+        cases["model embeddings"] = m_(feat)[0].contiguous()
+    for name, e in cases.items():
+        for centred in (False, True):
+            p = order(e, centred)
+            es = e[p].contiguous()
+            t, lab = timed(lambda: cluster_embeddings(es))
+            x = normalize_rows(es)
+            nb = n // 128
+            xb = x[:nb * 128].view(nb, 128, 64)
+            rad = (xb - xb.mean(1, keepdim=True)).norm(dim=2).max(1).values
+            print(f"{name:18s} centred {centred!s:5s}  {t:6.2f} ms   block radius median {float(rad.median()):.3f}  clusters {int(lab.max())}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
