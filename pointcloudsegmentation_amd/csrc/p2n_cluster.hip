@@ -992,12 +992,14 @@ __global__ __launch_bounds__(256) void cl_relist_kernel(const unsigned char *__r
     // at or after the row block's own; after it pass 1's list is that half, so every block is a candidate again, and
     // for the blocks before its own the row block finds its hits filed under the OTHER side (the workgroup that held
     // block jb as rows against this row block's two blocks as columns: a superset at that side's 256-row granularity).
-    const bool all = sym && !reach;
+    // With the reach notes every block is a candidate as well (a note both ways round implies that the spheres reach, so
+    // the sphere lists of cl_active_kernel are only built when the reach stage is switched off).
+    const bool all = sym || reach;
     const int total = all ? nb : act_cnt[ib];
     int *list = act_list + (long)ib * nb;
     if (t == 0) base = 0;
     __syncthreads();
-    for (int e0 = 0; e0 < total; e0 += 256) {
+    for (int e0 = (reach && sym) ? (2 * ib) & ~255 : 0; e0 < total; e0 += 256) {   // (reach && sym: nothing before the row block's own blocks)
         const int e = e0 + t;
         int jb = 0, keep = 0;
         if (e < total) {
@@ -1483,8 +1485,9 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const int nb128 = (int)(Npad / 128);
     hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (3 * 8 * G + 4), stream, w.Xp, w.nrm, G, w.centre,
                        w.radius);
-    hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
-                       8 * G, (float)eps, w.act_cnt, w.act_list);
+    if (!p2n_cluster_refines())
+        hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
+                           8 * G, (float)eps, w.act_cnt, w.act_list);
     const int sym = p2n_cluster_refines() && p2n_cluster_symmetric();   // (the halved lists are made by the reach stage's relist)
     if (p2n_cluster_refines()) {
         P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));

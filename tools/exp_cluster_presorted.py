@@ -107,3 +107,26 @@ for variant, seed in (("hash", 0), ("murmur", 0), ("torch", 5), ("torch", 6), ("
         p = torch.sort(key, stable=True).indices
         es = e[p].contiguous()
         print(f"variant {variant}/{seed}, delta {delta}:", *stages(es)[:2], flush=True)
+
+print("--- thresholds moved off the mean to the emptiest of a few candidates, then ranked by near mass", flush=True)
+S = torch.from_numpy(sign_matrix(64, "hash")).to(e.device)
+pr0 = xn @ S
+for ncand, span in ((1, 0.0), (5, 0.5), (9, 0.5), (9, 1.0)):
+    mu, sd = pr0.mean(0), pr0.std(0)
+    best_t, best_near = None, None
+    for c in range(ncand):
+        off = 0.0 if ncand == 1 else (c / (ncand - 1) - 0.5) * 2 * span
+        t = mu + off * sd
+        near = ((pr0 - t).abs() < 0.1).float().sum(0) + 1e-3 * abs(off) * pr0.shape[0]     # slight preference for balanced cuts
+        if best_t is None:
+            best_t, best_near = t.clone(), near.clone()
+        else:
+            take = near < best_near
+            best_t = torch.where(take, t, best_t); best_near = torch.where(take, near, best_near)
+    rank = torch.argsort(best_near)
+    ex = torch.empty(32, dtype=torch.int64, device=e.device)
+    ex[rank] = torch.arange(31, -1, -1, device=e.device)
+    key = (((pr0 - best_t) > 0).long() * (2 ** ex)).sum(1)
+    p = torch.sort(key, stable=True).indices
+    es = e[p].contiguous()
+    print(f"candidates {ncand}, span {span} sd:", *stages(es)[:2], flush=True)
