@@ -968,12 +968,20 @@ __global__ __launch_bounds__(256) void cl_reach_kernel(const float *__restrict__
             acc = MFMAB(bh, al[ks], acc);
             acc = MFMAB(bl, ah[ks], acc);
         }
+        // register r of lane half h belongs to centre 8 (r / 4) + 4 h + r % 4 of the tile: the 32 votes are collected in
+        // two scalar masks (bit r: some lane of that half reaches), then lane L < 32 writes centre L's byte -- one store
+        // per tile instead of thirty-two branches
+        unsigned m0 = 0u, m1 = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned long long m = __builtin_amdgcn_ballot_w64(acc[r] >= hx);
-            const unsigned half = h ? (unsigned)(m >> 32) : (unsigned)m;   // the two lane halves hold different centres
-            const int col = jt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-            if ((lane & 31) == 0 && half && col < nb) reach[A * nb + col] = 1;   // four waves may write the same 1
+            m0 |= ((unsigned)m != 0u ? 1u : 0u) << r;
+            m1 |= ((unsigned)(m >> 32) != 0u ? 1u : 0u) << r;
+        }
+        {
+            const int L = lane & 31, r = 4 * (L >> 3) + (L & 3), col = jt * 32 + L;
+            const unsigned mm = (L >> 2) & 1 ? m1 : m0;
+            if (lane < 32 && (mm >> r & 1u) && col < nb) reach[A * nb + col] = 1;   // four waves may write the same 1
         }
     }
 }

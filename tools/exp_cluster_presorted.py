@@ -130,3 +130,16 @@ for ncand, span in ((1, 0.0), (5, 0.5), (9, 0.5), (9, 1.0)):
     p = torch.sort(key, stable=True).indices
     es = e[p].contiguous()
     print(f"candidates {ncand}, span {span} sd:", *stages(es)[:2], flush=True)
+
+print("--- more candidate projections than bits: the 32 with the least near mass, ranked", flush=True)
+for ncand in (32, 64, 128):
+    g = torch.Generator(device="cpu").manual_seed(11)
+    S = (torch.randint(0, 2, (64, ncand), generator=g).float() * 2 - 1).to(e.device)
+    pr = xn @ S
+    pr = pr - pr.mean(0, keepdim=True)
+    near = (pr.abs() < 0.1).float().sum(0)
+    rank = torch.argsort(near)[:32]
+    key = ((pr[:, rank] > 0).long() * (2 ** torch.arange(31, -1, -1, device=e.device))).sum(1)
+    p = torch.sort(key, stable=True).indices
+    es = e[p].contiguous()
+    print(f"candidates {ncand}:", *stages(es)[:2], flush=True)
