@@ -321,6 +321,11 @@ struct ClArgs {
     // work_meta[0] chunks in all, one workgroup each
     const int *work_rb, *work_e0, *work_meta;
     int nsplit;   // pass 2: workgroups per row block
+    // pass 2 notes (D <= 64, -1 = none yet): blk_uni[b] = a parent that EVERY core point of block b named at some moment,
+    // rb_uni[rb] = a parent every row of row block rb named when one of its workgroups finished -- and all its real rows
+    // are core points.  Sets only grow, so "same root now" proves for good that a cell can join nothing and holds no row
+    // that needs a neighbour list: later workgroups of the row block strike such cells before anything is staged.
+    int *blk_uni, *rb_uni;
     const int *act_cnt;     // per 256-point row block (one workgroup): number of active 128-point blocks
     const int *act_list;    // [row block][nb128]: their indices, ascending
     int nb128;
@@ -391,10 +396,45 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         e0 = (int)((long)total * blockIdx.y / A.nsplit);
         e1 = (int)((long)total * (blockIdx.y + 1) / A.nsplit);
     }
-    const long len = (long)(e1 - e0) * SUB;
-    if (len <= 0) return;
+    int nlist = e1 - e0;
+    if (nlist <= 0) return;
     int *slist = reinterpret_cast<int *>(lds + CL_LDS_FLOATS);   // this workgroup's slice of the list
-    for (int i = threadIdx.x; i < e1 - e0; i += CL_NW * 64) slist[i] = A.act_list[(long)rb * A.nb128 + e0 + i];
+    for (int i = threadIdx.x; i < nlist; i += CL_NW * 64) slist[i] = A.act_list[(long)rb * A.nb128 + e0 + i];
+    if (MODE == 1 && SUB == 1 && A.rb_uni) {
+        int *scr = reinterpret_cast<int *>(lds);   // (the ring is not in use yet)
+        if (threadIdx.x == 0) scr[15] = CL_LD(A.rb_uni + rb);   // one reader: the note may be written while we look
+        __syncthreads();
+        const int rr = scr[15];
+        if (rr >= 0) {   // an earlier workgroup of this row block left its rows in one set: strike what is in that set already
+            const int r0 = cl_find(A.parent, rr);
+            int kept = 0;
+            for (int c0 = 0; c0 < nlist; c0 += CL_NW * 64) {   // compaction in place, 512 entries at a time
+                const int e = c0 + (int)threadIdx.x;
+                int B = 0;
+                bool keep = false;
+                if (e < nlist) {
+                    B = slist[e];
+                    const int bu = CL_LD(A.blk_uni + B);
+                    keep = !(bu >= 0 && cl_find(A.parent, bu) == r0);
+                }
+                const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                if (lane == 0) scr[wave] = __builtin_popcountll(km);
+                __syncthreads();
+                int off = kept, tot = 0;
+                for (int w2 = 0; w2 < CL_NW; ++w2) {
+                    if (w2 < wave) off += scr[w2];
+                    tot += scr[w2];
+                }
+                __syncthreads();   // every thread holds its entry and has read the wave counts
+                if (keep) slist[off + __builtin_popcountll(km & ((1ull << lane) - 1ull))] = B;
+                kept += tot;
+            }
+            nlist = kept;
+            __syncthreads();
+            if (nlist == 0) return;
+        }
+    }
+    const long len = (long)nlist * SUB;
     if (MODE == 1 && threadIdx.x < 8) lds[CL_PU_BASE + threadIdx.x] = __int_as_float(-1);   // pass 2, a wave that stages no parents: "no core point"
     // MODE 2: the three parent slots of pass 2 serve as rotating column counters (block t uses slot t % 3: its last
     // unit is compared during block t+1's first step, and it is flushed to cnt[] at the entry of block t+2)
@@ -706,6 +746,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
                     const int cp = (c0 == -2 || c1 == -2 || (c0 >= 0 && c1 >= 0 && c0 != c1)) ? -2 : (c0 > c1 ? c0 : c1);
                     const bool settled = hh == __builtin_inff() || (mycore && pi == cp);
                     if (cp == -1 || (cp >= 0 && !__builtin_amdgcn_ballot_w64(!settled))) blk_active = false;
+                    if (SUB == 1 && A.blk_uni && cp >= 0 && threadIdx.x == 0) CL_ST(A.blk_uni + jb_cur, cp);
                 }
             }
             active = blk_active;
@@ -769,6 +810,40 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
     for (long w = 0; w <= W; w += 2) {
         unit_step(accA, accB, w, std::integral_constant<int, 0>{});
         if (w + 1 <= W) unit_step(accB, accA, w + 1, std::integral_constant<int, (UPS > 1 ? 1 : 0)>{});
+    }
+    if (MODE == 1 && SUB == 1 && A.rb_uni) {
+        // do all rows of this row block name one root now, and is every real row a core point?
+        int *scr = reinterpret_cast<int *>(lds);
+        __syncthreads();   // (everybody is done with the ring)
+        const bool pad = hh == __builtin_inff();
+        int pr = -1;
+        if (mycore) {
+            pr = cl_find(A.parent, pi);
+            if (pr != (int)my && h == 0) CL_ST(A.parent + my, pr);   // a non-root's parent, only ever shortened: the rows leave flat,
+        }                                                          // so whoever streams them as columns finds one parent
+        const unsigned long long cm = __builtin_amdgcn_ballot_w64(mycore);
+        const int first = cm ? __builtin_amdgcn_readlane(pr, __builtin_ctzll(cm)) : -1;
+        const bool split = __builtin_amdgcn_ballot_w64(mycore && pr != first) != 0;    // core rows under different roots
+        const bool stray = __builtin_amdgcn_ballot_w64(!pad && !mycore) != 0;          // a real row that is not a core point
+        if (lane == 0) {
+            scr[wave] = split ? -2 : first;
+            scr[8 + wave] = stray;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {   // 0, 1: the row block's two blocks of 128 (core rows only matter); 2: the row block
+            const int w0 = threadIdx.x == 1 ? 4 : 0, w1 = threadIdx.x == 0 ? 4 : CL_NW;
+            int r = -1, bad = 0;
+            for (int w2 = w0; w2 < w1; ++w2) {
+                const int v = scr[w2];
+                r = (r == -2 || v == -2) ? -2 : (v == -1 ? r : (r == -1 || r == v) ? v : -2);
+                bad |= scr[8 + w2];
+            }
+            if (threadIdx.x < 2) {
+                if (r >= 0) CL_ST(A.blk_uni + 2 * rb + (int)threadIdx.x, r);
+            } else if (r >= 0 && !bad) {
+                CL_ST(A.rb_uni + rb, r);
+            }
+        }
     }
     if (MODE == 1) {
 #pragma unroll
@@ -1295,6 +1370,7 @@ struct ClWs {
     unsigned *key_a, *key_b;   // working order: code of every row, double-buffered for the sort
     int *perm, *val_b;         // working row -> caller's index (the sort's values)
     int *minorig, *owner, *chunk_cnt;
+    int *blk_uni, *rb_uni;
     void *sort_tmp;
     size_t sort_tmp_bytes;
     int *defer_q, *defer_cnt;
@@ -1361,6 +1437,8 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
     w.val_b = (int *)take(sizeof(int) * Npad);
     w.minorig = (int *)take(sizeof(int) * Npad);
     w.owner = (int *)take(sizeof(int) * Npad);
+    w.blk_uni = (int *)take(sizeof(int) * (Npad / 128 + 2));
+    w.rb_uni = (int *)take(sizeof(int) * (Npad / 256 + 2));
     w.chunk_cnt = (int *)take(sizeof(int) * (Npad / (1024 * CL_RANK_PT) + 2));
     w.sort_tmp_bytes = (size_t)Npad * 8 + (4u << 20);   // the double-buffered radix sort needs its digit counts only; checked at the call
     w.sort_tmp = take(w.sort_tmp_bytes);
@@ -1416,6 +1494,11 @@ static bool p2n_cluster_sorts(long N) {
 
 static bool p2n_cluster_symmetric() {
     const char *e = getenv("P2N_CL_SYM");
+    return !(e && atoi(e) == 0);
+}
+
+static bool p2n_cluster_link_notes() {
+    const char *e = getenv("P2N_CL_NOTES");
     return !(e && atoi(e) == 0);
 }
 
@@ -1553,6 +1636,12 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     hipLaunchKernelGGL(cl_relist_kernel, dim3((unsigned)nrowblk), dim3(256), 0, stream, w.hit, w.blk_has_core, (const unsigned char *)nullptr, nb128, sym, w.act_cnt,
                        w.act_list);
     a.nsplit = cl_nsplit(Npad);
+    a.blk_uni = nullptr; a.rb_uni = nullptr;
+    if (p2n_cluster_link_notes()) {
+        P2N_CHECK_HIP(hipMemsetAsync(w.blk_uni, 0xff, sizeof(int) * (Npad / 128 + 2), stream));
+        P2N_CHECK_HIP(hipMemsetAsync(w.rb_uni, 0xff, sizeof(int) * (Npad / 256 + 2), stream));
+        a.blk_uni = w.blk_uni; a.rb_uni = w.rb_uni;
+    }
     if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, (int)nrowblk, stream);
     else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, (int)nrowblk, stream);
     else rc = cl_launch_pairs<32, 1>(1, a, (int)nrowblk, stream);
