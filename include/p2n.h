@@ -354,8 +354,8 @@ int p2n_gather_xyz(const float *xyz, int ldx, const int32_t *idx, int B, int N, 
  * pruning needs rows that are close in the embedding to be close in the index); results do not
  * depend on it: labels, cluster numbers and counts refer to the caller's row indices.
  * Environment: P2N_CL_SORT=0 works in the given order, P2N_CL_REACH=0 prunes by bounding spheres
- * only, P2N_CL_SYM=0 lets the count pass visit every block pair from both sides (all read per
- * call; for tests and A/B timings).
+ * only, P2N_CL_SYM=0 lets the count pass visit every block pair from both sides, P2N_CL_NOTES=0
+ * switches the link pass's settled-block notes off (all read per call; for tests and A/B timings).
  * p2n_cluster_counts copies out the neighbourhood sizes the last call left in `workspace`. */
 int p2n_normalize_rows(const float *emb, long N, int D, float *out, void *stream);
 size_t p2n_cluster_workspace_bytes(long N, int D, int min_samples);

@@ -151,7 +151,7 @@ def test_shuffled_rows_get_the_same_partition_numbered_by_first_index():
     assert bool((first[1:-1] < first[2:]).all())
 
 
-@pytest.mark.parametrize("env", [{"P2N_CL_SYM": "0"}, {"P2N_CL_REACH": "0"}, {"P2N_CL_SYM": "0", "P2N_CL_SORT": "0"}])
+@pytest.mark.parametrize("env", [{"P2N_CL_SYM": "0"}, {"P2N_CL_REACH": "0"}, {"P2N_CL_SYM": "0", "P2N_CL_SORT": "0"}, {"P2N_CL_NOTES": "0"}])
 @pytest.mark.parametrize("N,D,k,ms,eps,order", [(12000, 64, 20, 40, 0.1, "random"), (6000, 200, 6, 20, 0.12, "runs"),
                                                 (7000, 128, 8, 25, 0.1, "random")])
 def test_pruning_stages_switched_off_change_nothing(monkeypatch, env, N, D, k, ms, eps, order):
