@@ -88,14 +88,68 @@ __device__ __forceinline__ float cl_np_sumsq(const float *e, int n) {
         return __builtin_nanf("");   // unreachable for n <= 256
 }
 
+// A thread per row reads its own row, and the lanes of a wave sit a whole row apart: every load instruction touches 64
+// lines for 16 bytes each, and the lines are long gone from the L1 when the next piece of the row is wanted
+// (cl_normalize_kernel ran at 1.3 TB/s, cl_project_kernel at 0.9).  So for D <= CL_STAGE_DMAX the workgroup first
+// copies its rows into LDS, a wave per row (whole lines, each fetched once), row r at tile + r * S with S odd: a
+// thread reading its own row from there meets no bank conflict.  The arithmetic is the same, value for value.
+#define CL_STAGE_DMAX 128
+#define CL_SUM_COPIES 16   // copies of the projections' sums and near-mean counts (cl_project_kernel)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define CL_STAGE_ROWS 128   // threads (= rows) per workgroup of the staged kernels: 128 * 129 floats = 64.5 KiB at most
+__device__ __forceinline__ int cl_stage_stride(int D) { return D | 1; }
+// a wave copies its 64 rows 16 at a time: 16 (or 32) independent loads in flight per lane, then the LDS stores (a row
+// at a time the copy was a chain of 64 memory round trips)
+template <int NC>   // 64-float pieces per row
+__device__ __forceinline__ void cl_stage_rows_nc(float *tile, int S, const float *__restrict__ emb, const int *__restrict__ perm,
+                                                 long i0, long N, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63);   // this wave's first row
+    const long left = N - i0;
+    const int nrows = left < (long)blockDim.x ? (int)(left < 0 ? 0 : left) : (int)blockDim.x;
+    const int mine = r0 + lane < nrows ? (perm ? perm[i0 + r0 + lane] : 0) : 0;   // lane l: the source row of row r0 + l
+    for (int rb = 0; rb < 64; rb += 16) {
+        if (r0 + rb >= nrows) break;
+        float v[16][NC];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = r0 + rb + u;
+            const long src = perm ? (long)__builtin_amdgcn_readlane(mine, rb + u) : i0 + r;
+            const float *e = emb + src * D;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = lane + 64 * q;
+                v[u][q] = (r < nrows && c < D) ? e[c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = lane + 64 * q;
+                if (c < D) tile[(r0 + rb + u) * S + c] = v[u][q];
+            }
+    }
+}
+__device__ __forceinline__ void cl_stage_rows(float *tile, int S, const float *__restrict__ emb, const int *__restrict__ perm,
+                                              long i0, long N, int D) {
+    if (D <= 64) cl_stage_rows_nc<1>(tile, S, emb, perm, i0, N, D);
+    else cl_stage_rows_nc<2>(tile, S, emb, perm, i0, N, D);
+    __syncthreads();
+}
+
 // thread per point.  out_rm (N,D) row-major and/or the fragment image Xp + fp32 squared norms.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restrict__ emb, long N, long Npad, int D, int G,
                                                            float *__restrict__ out_rm, float *__restrict__ Xp,
                                                            float *__restrict__ nrm, float *__restrict__ Xb,
                                                            const int *__restrict__ perm) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Npad) return;
-    if (i >= N) {   // pad rows: zero vectors that are never anybody's neighbour
+    extern __shared__ float tile[];   // STAGED: [blockDim.x][D | 1]
+    const long i0 = (long)blockIdx.x * blockDim.x;
+    const long i = i0 + threadIdx.x;
+    const int S = cl_stage_stride(D);
+    if constexpr (STAGED) cl_stage_rows(tile, S, emb, perm, i0, N, D);
+    if (i < Npad && i >= N) {   // pad rows: zero vectors that are never anybody's neighbour
         if (Xp) {
             for (int k = 0; k < G * 8; k += 4) {
                 const int g = k >> 3, h = (k >> 2) & 1;
@@ -104,38 +158,64 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
             }
             nrm[i] = -__builtin_inff();
         }
-        return;
     }
-    const float *e = emb + (perm ? (long)perm[i] : i) * D;   // row i of the working order
-    const float ss = cl_np_sumsq<2>(e, D);
-    // sqrt and divide through double: correctly rounded in fp32 (53 >= 2*24+2) whatever the fp32 fast paths do
-    const float den = __fadd_rn((float)sqrt((double)ss), 1e-8f);
-    double sq = 0.0;
-    for (int k = 0; k < G * 8; k += 4) {
-        f32x4 v;
+    if (i < N) {
+        float *mine = tile + threadIdx.x * S;
+        const float *eg = emb + (perm ? (long)perm[i] : i) * D;   // row i of the working order
+        float ss;
+        if constexpr (STAGED) ss = cl_np_sumsq<2>(mine, D);
+        else ss = cl_np_sumsq<2>(eg, D);
+        // sqrt and divide through double: correctly rounded in fp32 (53 >= 2*24+2) whatever the fp32 fast paths do
+        const float den = __fadd_rn((float)sqrt((double)ss), 1e-8f);
+        double sq = 0.0;
+        for (int k = 0; k < G * 8; k += 8) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = (k + j < D) ? (float)((double)e[k + j] / (double)den) : 0.f;
-            sq += (double)v[j] * (double)v[j];
-            if (out_rm && k + j < D) out_rm[i * D + k + j] = v[j];
-        }
-        if (Xp) {
-            const int g = k >> 3, h = (k >> 2) & 1;
-            *reinterpret_cast<f32x4 *>(Xp + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = v;
-            // split image: dims k..k+3 are elements 4*(k/4 % 2).. of lane half (k/8 % 2) of k-step k/16
-            const int ks = k >> 4, hb = (k >> 3) & 1, e0 = k & 4;
-            unsigned short *fh = reinterpret_cast<unsigned short *>(Xb + (((i >> 5) * G + 2 * ks) * 64 + hb * 32 + (i & 31)) * 4);
-            unsigned short *fl = fh + 512;   // the lo fragment follows the hi fragment (1 KiB = 512 halves)
+            for (int j = 0; j < 8; ++j) {
+                float x = 0.f;
+                if (k + j < D) {
+                    if constexpr (STAGED) x = mine[k + j];
+                    else x = eg[k + j];
+                }
+                v[j] = (k + j < D) ? (float)((double)x / (double)den) : 0.f;
+                sq += (double)v[j] * (double)v[j];
+                if (out_rm && k + j < D) {
+                    if constexpr (STAGED) mine[k + j] = v[j];   // (copied out by whole lines below)
+                    else out_rm[i * D + k + j] = v[j];
+                }
+            }
+            if (Xp) {
+                const int g = k >> 3;
+                float *xp = Xp + (((i >> 5) * G + g) * 64 + (i & 31)) * 4;
+                *reinterpret_cast<f32x4 *>(xp) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4 *>(xp + 128) = f32x4{v[4], v[5], v[6], v[7]};
+                // split image: dims k..k+7 are the 8 elements of lane half (k/8 % 2) of k-step k/16, one 16-byte piece
+                const int ks = k >> 4, hb = (k >> 3) & 1;
+                float *fh = Xb + (((i >> 5) * G + 2 * ks) * 64 + hb * 32 + (i & 31)) * 4;
+                unsigned hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const __bf16 hi = (__bf16)v[j];
-                const __bf16 lo = (__bf16)(v[j] - (float)hi);
-                fh[e0 + j] = __builtin_bit_cast(unsigned short, hi);
-                fl[e0 + j] = __builtin_bit_cast(unsigned short, lo);
+                for (int j = 0; j < 4; ++j) {
+                    const __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
+                    const __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
+                    hi[j] = (unsigned)__builtin_bit_cast(unsigned short, h0) | (unsigned)__builtin_bit_cast(unsigned short, h1) << 16;
+                    lo[j] = (unsigned)__builtin_bit_cast(unsigned short, l0) | (unsigned)__builtin_bit_cast(unsigned short, l1) << 16;
+                }
+                *reinterpret_cast<u32x4 *>(fh) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<u32x4 *>(fh + 256) = u32x4{lo[0], lo[1], lo[2], lo[3]};   // the lo fragment follows the hi fragment (1 KiB)
             }
         }
+        if (Xp) nrm[i] = (float)(-0.5 * sq);   // nh = -|x|^2/2, the accumulator start value of the pair passes
     }
-    if (Xp) nrm[i] = (float)(-0.5 * sq);   // nh = -|x|^2/2, the accumulator start value of the pair passes
+    if constexpr (STAGED) {
+        if (out_rm) {   // rows i0.. are one stretch of out_rm
+            __syncthreads();
+            const long left = N - i0;
+            const int nrows = left < (long)blockDim.x ? (int)(left < 0 ? 0 : left) : (int)blockDim.x;
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+            for (int r = wave; r < nrows; r += nw)
+                for (int c = lane; c < D; c += 64) out_rm[(i0 + r) * D + c] = tile[r * S + c];
+        }
+    }
 }
 
 // ------------------------------------------------------------------ working order
@@ -148,25 +228,48 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
 // The projections are taken about their MEANS over the scene: embeddings that fill a small part of the sphere are
 // rarely cut by hyperplanes through the origin (nearly every bit would be the same for every row).
 // Step 1: proj[i][k] = (x_i / |x_i|) . r_k, and their sums over the rows (LDS per workgroup, then 32 atomics).
+// the +-1 of dimension d in projection k: bit k of a hash of d, as a float; D <= 256
+struct ClSigns { float v[256 * 32]; };
+constexpr ClSigns cl_make_signs() {
+    ClSigns s{};
+    for (int d = 0; d < 256; ++d) {
+        unsigned hsh = (unsigned)d * 0x9E3779B1u + 0x7F4A7C15u;
+        hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
+        for (int k = 0; k < 32; ++k) s.v[d * 32 + k] = (hsh >> k & 1u) ? -1.f : 1.f;
+    }
+    return s;
+}
+__constant__ ClSigns cl_signs = cl_make_signs();
+
+template <bool STAGED>
 __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict__ emb, long N, int D, float *__restrict__ proj,
                                                          float *__restrict__ psum) {
     __shared__ float part[4][32];
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ float tile[];   // STAGED: [blockDim.x][D | 1] (cl_stage_rows)
+    const long i0 = (long)blockIdx.x * blockDim.x;
+    const long i = i0 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int S = cl_stage_stride(D);
+    if constexpr (STAGED) cl_stage_rows(tile, S, emb, nullptr, i0, N, D);
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.f;
     if (i < N) {
         const float *e = emb + i * D;
+        const float *mine = tile + threadIdx.x * S;
         float ss = 0.f;
+        // (d is the same in every lane: the 32 signs of dimension d come from the table as scalar loads and meet x as
+        // the +-1.0 operand of one fma per projection -- x * +-1 is exact, so the sum is the same as adding +-x.
+        // Made in the kernel, per dimension, they were ~100 scalar or vector instructions, most of this kernel's time)
         auto dim = [&](int d, float x) __attribute__((always_inline)) {
-            unsigned hsh = (unsigned)d * 0x9E3779B1u + 0x7F4A7C15u;   // the 32 signs of dimension d
-            hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
+            const float *sg = cl_signs.v + __builtin_amdgcn_readfirstlane(d) * 32;
             ss = fmaf(x, x, ss);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) acc[k] += __uint_as_float(__float_as_uint(x) ^ ((hsh >> k & 1u) << 31));
+            for (int k = 0; k < 32; ++k) acc[k] = fmaf(x, sg[k], acc[k]);
         };
-        if ((D & 3) == 0 && (reinterpret_cast<size_t>(emb) & 15) == 0) {   // rows of whole 16-byte pieces: a quarter of the loads
+        if constexpr (STAGED) {
+            for (int d = 0; d < D; ++d) dim(d, mine[d]);
+        } else if ((D & 3) == 0 && (reinterpret_cast<size_t>(emb) & 15) == 0) {   // rows of whole 16-byte pieces: a quarter of the loads
             for (int d = 0; d < D; d += 4) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(e + d);
 #pragma unroll
@@ -181,19 +284,50 @@ __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict
             acc[k] *= inv;
             if (!(acc[k] == acc[k])) acc[k] = 0.f;   // a row with a NaN or an infinity: any code will do, but keep it out of the means
         }
+        if constexpr (!STAGED) {
 #pragma unroll
-        for (int k = 0; k < 32; k += 4)
-            *reinterpret_cast<f32x4 *>(proj + i * 32 + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+            for (int k = 0; k < 32; k += 4)
+                *reinterpret_cast<f32x4 *>(proj + i * 32 + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+        }
     }
+    if constexpr (STAGED) {
+        // the 32 results go over the first 32 floats of the thread's own row (D >= 32 here), and leave as whole lines:
+        // the workgroup's rows of proj are one stretch of memory; the column sums are taken from the tile as well
+        float *mine = tile + threadIdx.x * S;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        float v = acc[k];
+        for (int k = 0; k < 32; ++k) mine[k] = acc[k];   // (zeros beyond row N)
+        __syncthreads();
+        const long left = N - i0;
+        const int nrows = left < (long)blockDim.x ? (int)left : (int)blockDim.x;
+        for (int idx = threadIdx.x; idx < nrows * 32; idx += blockDim.x) proj[i0 * 32 + idx] = tile[(idx >> 5) * S + (idx & 31)];
+        const int c = threadIdx.x & 31, q = threadIdx.x >> 5, per = blockDim.x >> 2;   // CL_STAGE_ROWS = 128 threads: four quarters
+        float v = 0.f;
+        for (int r = q * per; r < (q + 1) * per; ++r) v += tile[r * S + c];
+        part[q][c] = v;
+    } else {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) part[wave][k] = v;
+        for (int k = 0; k < 32; ++k) {
+            float v = acc[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) part[wave][k] = v;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 32) atomicAdd(psum + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < 32) {
+        float v = 0.f;
+        for (int w = 0; w < (STAGED ? 4 : nw); ++w) v += part[w][threadIdx.x];
+        // CL_SUM_COPIES copies of the 32 sums, a workgroup adds to copy blockIdx % CL_SUM_COPIES: atomics on one line
+        // take their turns in the L2
+        atomicAdd(psum + (blockIdx.x % CL_SUM_COPIES) * 32 + threadIdx.x, v);
+    }
+}
+
+// mean of projection k: the copies of its sum in a fixed order (every kernel that wants the mean gets the same value)
+__device__ __forceinline__ float cl_proj_mean(const float *__restrict__ psum, int k, long N) {
+    float t = 0.f;
+    for (int c = 0; c < CL_SUM_COPIES; ++c) t += psum[c * 32 + k];
+    return t * (1.f / (float)N);
 }
 
 // Step 2: how many rows sit within `delta` (= eps) of each projection's mean.  A hyperplane that passes through an
@@ -204,33 +338,45 @@ __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void cl_near_kernel(const float *__restrict__ proj, const float *__restrict__ psum, long N,
                                                       float delta, int *__restrict__ near) {
     __shared__ int part[4][32];
+    __shared__ float mean[32];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float invn = 1.f / (float)N;
+    if (threadIdx.x < 32) mean[threadIdx.x] = cl_proj_mean(psum, threadIdx.x, N);
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 32; k += 4) {
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (i < N) v = *reinterpret_cast<const f32x4 *>(proj + i * 32 + k);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(i < N && fabsf(v[j] - psum[k + j] * invn) < delta);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(i < N && fabsf(v[j] - mean[k + j]) < delta);
             if (lane == 0) part[wave][k + j] = (int)__builtin_popcountll(m);
         }
     }
     __syncthreads();
-    if (threadIdx.x < 32) atomicAdd(near + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < 32)
+        atomicAdd(near + (blockIdx.x % CL_SUM_COPIES) * 32 + threadIdx.x,
+                  part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // Step 3: bit = projection above its mean, at position 31 - (rank of the projection by mass near its mean, ascending).
 __global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ proj, const float *__restrict__ psum,
                                                       const int *__restrict__ near, long N, unsigned *__restrict__ keys,
                                                       int *__restrict__ vals) {
-    __shared__ int pos[32];
+    __shared__ int pos[32], mass[32];
+    __shared__ float mean[32];
     if (threadIdx.x < 32) {
-        const int mine = near[threadIdx.x];
+        int m = 0;
+        for (int c = 0; c < CL_SUM_COPIES; ++c) m += near[c * 32 + threadIdx.x];
+        mass[threadIdx.x] = m;
+        mean[threadIdx.x] = cl_proj_mean(psum, threadIdx.x, N);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int mine = mass[threadIdx.x];
         int rank = 0;
         for (int j = 0; j < 32; ++j) {
-            const int o = near[j];
+            const int o = mass[j];
             rank += (o < mine) || (o == mine && j < (int)threadIdx.x);
         }
         pos[threadIdx.x] = 31 - rank;
@@ -238,13 +384,12 @@ __global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ 
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const float invn = 1.f / (float)N;
     unsigned key = 0;
 #pragma unroll
     for (int k = 0; k < 32; k += 4) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(proj + i * 32 + k);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) key |= (unsigned)(v[j] > psum[k + j] * invn) << pos[k + j];
+        for (int j = 0; j < 4; ++j) key |= (unsigned)(v[j] > mean[k + j]) << pos[k + j];
     }
     keys[i] = key;
     vals[i] = (int)i;
@@ -1478,14 +1623,32 @@ extern "C" size_t p2n_cluster_workspace_bytes(long N, int D, int min_samples) {
     return cl_carve(w, nullptr, (N + CL_NPAD_UNIT - 1) / CL_NPAD_UNIT * CL_NPAD_UNIT, G, N, min_samples - 1);
 }
 
+static size_t cl_stage_lds_bytes(int D) { return sizeof(float) * CL_STAGE_ROWS * (size_t)(D | 1); }
+
+// rows staged through LDS up to CL_STAGE_DMAX dimensions, read in place above that
+static int cl_launch_normalize(const float *emb, long N, long Npad, int D, int G, float *out_rm, float *Xp, float *nrm, float *Xb,
+                               const int *perm, hipStream_t stream) {
+    if (D <= CL_STAGE_DMAX) {
+        const size_t ldsb = cl_stage_lds_bytes(D);
+        P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_normalize_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        hipLaunchKernelGGL(cl_normalize_kernel<true>, dim3((unsigned)((Npad + CL_STAGE_ROWS - 1) / CL_STAGE_ROWS)), dim3(CL_STAGE_ROWS), ldsb,
+                           stream, emb, N, Npad, D, G, out_rm, Xp, nrm, Xb, perm);
+    } else {
+        hipLaunchKernelGGL(cl_normalize_kernel<false>, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, stream, emb, N, Npad, D, G,
+                           out_rm, Xp, nrm, Xb, perm);
+    }
+    P2N_CHECK_HIP(hipGetLastError());
+    return P2N_OK;
+}
+
 extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, void *stream_) {
     P2N_REQUIRE(N >= 0 && D >= 1 && D <= 256, "p2n_normalize_rows: N=%ld D=%d (D in 1..256)", N, D);
     if (N == 0) return P2N_OK;
     P2N_REQUIRE(emb && out, "p2n_normalize_rows: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(cl_normalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, N, D, (D + 7) / 8,
-                       out, (float *)nullptr, (float *)nullptr, (float *)nullptr, (const int *)nullptr);
-    P2N_CHECK_HIP(hipGetLastError());
+    int rc = cl_launch_normalize(emb, N, N, D, (D + 7) / 8, out, nullptr, nullptr, nullptr, nullptr, stream);
+    if (rc) return rc;
     return P2N_OK;
 }
 
@@ -1556,11 +1719,19 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     const int *perm = nullptr;
     if (p2n_cluster_sorts(N)) {   // the working order (cl_code_kernel)
         // (the projections borrow Xp, which cl_normalize_kernel fills afterwards: 32 of its >= 64 floats per row; their
-        // sums and near-threshold counts the first 64 words of the sort's scratch, which the sort does not touch before cl_code_kernel has run)
+        // sums and near-threshold counts (CL_SUM_COPIES copies of each) the first 1,024 words of the sort's scratch, which the sort does not touch before cl_code_kernel has run)
         float *psum = reinterpret_cast<float *>(w.sort_tmp);
-        int *near = reinterpret_cast<int *>(psum + 32);
-        P2N_CHECK_HIP(hipMemsetAsync(psum, 0, 64 * sizeof(float), stream));
-        hipLaunchKernelGGL(cl_project_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, D, w.Xp, psum);
+        int *near = reinterpret_cast<int *>(psum + 32 * CL_SUM_COPIES);
+        P2N_CHECK_HIP(hipMemsetAsync(psum, 0, 64 * CL_SUM_COPIES * sizeof(float), stream));
+        if (D >= 32 && D <= CL_STAGE_DMAX) {   // (the staged kernel hands its 32 results out through the row's own LDS)
+            const size_t ldsb = cl_stage_lds_bytes(D);
+            P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_project_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(cl_project_kernel<true>, dim3((unsigned)((N + CL_STAGE_ROWS - 1) / CL_STAGE_ROWS)), dim3(CL_STAGE_ROWS), ldsb,
+                               stream, emb, N, D, w.Xp, psum);
+        } else {
+            hipLaunchKernelGGL(cl_project_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, D, w.Xp, psum);
+        }
         hipLaunchKernelGGL(cl_near_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, N, (float)eps, near);
         hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, near, N, w.key_a, w.perm);
         rocprim::double_buffer<unsigned> kb(w.key_a, w.key_b);
@@ -1574,8 +1745,8 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         P2N_CHECK_HIP(hipMemsetAsync(w.stats + 7, 1, 1, stream));   // stats[7] = 1: this workspace holds a working order
         perm = w.perm;
     }
-    hipLaunchKernelGGL(cl_normalize_kernel, dim3(nb256), dim3(256), 0, stream, emb, N, Npad, D, G, (float *)nullptr, w.Xp, w.nrm, w.Xb,
-                       perm);
+    rc = cl_launch_normalize(emb, N, Npad, D, G, nullptr, w.Xp, w.nrm, w.Xb, perm, stream);
+    if (rc) return rc;
     const int nb128 = (int)(Npad / 128);
     hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (3 * 8 * G + 4), stream, w.Xp, w.nrm, G, w.centre,
                        w.radius);
