@@ -131,9 +131,42 @@ __device__ __forceinline__ void cl_stage_rows_nc(float *tile, int S, const float
             }
     }
 }
+// rows of 32, 64 or 128 floats at 16-byte addresses: 16-byte loads, 64 >> LOG_P4 rows per instruction (four times the
+// bytes in flight per wave: the staged kernels run few waves per CU, their LDS is the rows)
+template <int LOG_P4>   // 16-byte pieces per row = 1 << LOG_P4
+__device__ __forceinline__ void cl_stage_rows_wide(float *tile, int S, const float *__restrict__ emb, const int *__restrict__ perm,
+                                                   long i0, long N, int D) {
+    constexpr int P4 = 1 << LOG_P4, RPI = 64 >> LOG_P4, NI = P4, BATCH = NI < 16 ? NI : 16;
+    const int lane = threadIdx.x & 63, sub = lane >> LOG_P4, c4 = lane & (P4 - 1);
+    const int r0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63);   // this wave's first row
+    const long left = N - i0;
+    const int nrows = left < (long)blockDim.x ? (int)(left < 0 ? 0 : left) : (int)blockDim.x;
+    const int mine = r0 + lane < nrows ? (perm ? perm[i0 + r0 + lane] : 0) : 0;   // lane l: the source row of row r0 + l
+    for (int b = 0; b < NI; b += BATCH) {
+        if (r0 + b * RPI >= nrows) break;
+        f32x4 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int r = (b + u) * RPI + sub;
+            const long src = perm ? (long)__shfl(mine, r) : i0 + r0 + r;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r0 + r < nrows) v[u] = *reinterpret_cast<const f32x4 *>(emb + src * D + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            float *t = tile + (r0 + (b + u) * RPI + sub) * S + c4 * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = v[u][j];   // (S is odd: four 4-byte stores; rows of other sub-groups land one bank on)
+        }
+    }
+}
 __device__ __forceinline__ void cl_stage_rows(float *tile, int S, const float *__restrict__ emb, const int *__restrict__ perm,
                                               long i0, long N, int D) {
-    if (D <= 64) cl_stage_rows_nc<1>(tile, S, emb, perm, i0, N, D);
+    const bool al = (reinterpret_cast<size_t>(emb) & 15) == 0;
+    if (al && D == 64) cl_stage_rows_wide<4>(tile, S, emb, perm, i0, N, D);
+    else if (al && D == 128) cl_stage_rows_wide<5>(tile, S, emb, perm, i0, N, D);
+    else if (al && D == 32) cl_stage_rows_wide<3>(tile, S, emb, perm, i0, N, D);
+    else if (D <= 64) cl_stage_rows_nc<1>(tile, S, emb, perm, i0, N, D);
     else cl_stage_rows_nc<2>(tile, S, emb, perm, i0, N, D);
     __syncthreads();
 }
@@ -268,7 +301,13 @@ __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict
             for (int k = 0; k < 32; ++k) acc[k] = fmaf(x, sg[k], acc[k]);
         };
         if constexpr (STAGED) {
-            for (int d = 0; d < D; ++d) dim(d, mine[d]);
+            int d = 0;
+            for (; d + 1 < D; d += 2) {   // (two dimensions' sign loads and LDS reads in flight)
+                const float x0 = mine[d], x1 = mine[d + 1];
+                dim(d, x0);
+                dim(d + 1, x1);
+            }
+            if (d < D) dim(d, mine[d]);
         } else if ((D & 3) == 0 && (reinterpret_cast<size_t>(emb) & 15) == 0) {   // rows of whole 16-byte pieces: a quarter of the loads
             for (int d = 0; d < D; d += 4) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(e + d);

@@ -25,7 +25,7 @@ def test_golden_labels(name):
     np.testing.assert_array_equal(got, g["labels"])
 
 
-@pytest.mark.parametrize("D", [1, 5, 8, 13, 64, 127, 128, 129, 200, 255, 256])
+@pytest.mark.parametrize("D", [1, 5, 8, 13, 31, 32, 33, 48, 64, 100, 127, 128, 129, 200, 255, 256])
 def test_normalize_rows_bit_exact(D):
     from pointcloudsegmentation_amd.clustering import normalize_rows
     e = np.random.default_rng(D).standard_normal((1000, D)).astype(np.float32) * 3
@@ -35,7 +35,8 @@ def test_normalize_rows_bit_exact(D):
 
 
 @pytest.mark.parametrize("N,D,k,ms,eps", [(20000, 64, 60, 50, 0.1), (9000, 64, 33, 50, 0.1), (5000, 128, 10, 25, 0.1),
-                                          (3000, 200, 6, 20, 0.12), (4097, 16, 20, 30, 0.08), (129, 64, 2, 5, 0.1)])
+                                          (3000, 200, 6, 20, 0.12), (4097, 16, 20, 30, 0.08), (129, 64, 2, 5, 0.1),
+                                          (5000, 32, 8, 25, 0.1), (4000, 100, 8, 25, 0.1)])
 def test_vs_oracle(N, D, k, ms, eps):
     from oracle import oracle
     from pointcloudsegmentation_amd.clustering import cluster_embeddings
