@@ -1071,8 +1071,38 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
 // Embeddings of one instance sit close together and scans are index-coherent, so most block pairs of a
 // scene are farther apart than eps and never need their 128 x 128 distance tile.
 #define CL_SPH_MARGIN 1e-4f   // fp32 slack of centre / radius / centre-distance arithmetic (vectors are unit length)
+// Centre i as one more row of the split-bf16 fragment layout of Xb (cl_normalize_kernel), 32 centres per tile, for
+// cl_reach_kernel, and its accumulator start value (R^2 - |c|^2) / 2, R = radius + eps + margin (-inf: empty block
+// or padding, cen == nullptr).  Called by a whole workgroup: thread k writes dimension k's two halves.
+__device__ __forceinline__ void cl_pack_centre(float *__restrict__ Cb, float *__restrict__ nhc, int G, int i, const float *cen,
+                                               float rad, float eps, int t, int nthreads) {
+    const int Dp = 8 * G;
+    for (int k = t; k < Dp; k += nthreads) {
+        const float v = cen ? cen[k] : 0.f;
+        const int ks = k >> 4, hb = (k >> 3) & 1, e = k & 7;
+        unsigned short *fh = reinterpret_cast<unsigned short *>(Cb + ((((long)i >> 5) * G + 2 * ks) * 64 + hb * 32 + (i & 31)) * 4);
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        fh[e] = __builtin_bit_cast(unsigned short, hi);
+        fh[512 + e] = __builtin_bit_cast(unsigned short, lo);   // the lo fragment follows the hi fragment
+    }
+    if (t == 0) {
+        float start = -__builtin_inff();
+        if (cen) {
+            float sq = 0.f;
+            for (int k = 0; k < Dp; ++k) sq = fmaf(cen[k], cen[k], sq);
+            const float R = rad + eps + CL_SPH_MARGIN;
+            start = 0.5f * (R * R - sq);
+        }
+        nhc[i] = start;
+    }
+}
+
+// (Cb != nullptr: the block's centre also goes into the reach stage's packed set, and the last block pads the set to
+// whole tiles of 32 -- a kernel of its own took 17 us for this)
 __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
-                                                        float *__restrict__ centre, float *__restrict__ radius) {
+                                                        float *__restrict__ centre, float *__restrict__ radius,
+                                                        float *__restrict__ Cb, float *__restrict__ nhc, int nb, int nbpad, float eps) {
     extern __shared__ float sph[];   // [8G] centre, [2][8G] the two waves' column sums, [4] scalars
     float *cen = sph, *part = sph + 8 * G, *sc = sph + 3 * 8 * G;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, Dp = 8 * G;
@@ -1090,9 +1120,12 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     }
     __syncthreads();
     const float cntf = sc[0] + sc[1];
+    if (Cb && b == nb - 1)
+        for (int i2 = nb; i2 < nbpad; ++i2) cl_pack_centre(Cb, nhc, G, i2, nullptr, 0.f, eps, t, 128);
     if (cntf == 0.f) {
         if (t == 0) radius[b] = -1.f;
         for (int k = t; k < Dp; k += 128) centre[(long)b * Dp + k] = 0.f;
+        if (Cb) cl_pack_centre(Cb, nhc, G, b, nullptr, 0.f, eps, t, 128);
         return;
     }
     for (int k = t; k < Dp; k += 128) cen[k] = (part[k] + part[Dp + k]) / cntf;
@@ -1107,8 +1140,10 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o));
     if (lane == 0) sc[2 + wave] = d2;
     __syncthreads();
-    if (t == 0) radius[b] = sqrtf(fmaxf(sc[2], sc[3])) + CL_SPH_MARGIN;
+    const float rad = sqrtf(fmaxf(sc[2], sc[3])) + CL_SPH_MARGIN;
+    if (t == 0) radius[b] = rad;
     for (int k = t; k < Dp; k += 128) centre[(long)b * Dp + k] = cen[k];   // (up to 256 dimensions, 128 threads)
+    if (Cb) cl_pack_centre(Cb, nhc, G, b, cen, rad, eps, t, 128);
 }
 
 // grid = row groups of 256 points.  list[ib][0..cnt) = column blocks jb (ascending) that can reach either of the
@@ -1163,33 +1198,6 @@ __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict_
 // the note holds both ways round.  An outlier block against a tight instance block fails the second half: none
 // of the outliers is near the instance.
 #define CL_REACH_SLACK 4e-5f   // on x.c - |c|^2/2: three-term bf16 split (<= 1.5e-5 for unit-length x, |c| <= 1) + fp32 accumulation + roundings of the terms
-// centres as one more row set in the split-bf16 fragment layout of Xb (cl_normalize_kernel), 32 centres per tile, and
-// per centre the accumulator start value (R^2 - |c|^2) / 2, R = radius + eps + margin (-inf: empty block or padding)
-__global__ __launch_bounds__(256) void cl_pack_centres_kernel(const float *__restrict__ centre, const float *__restrict__ radius,
-                                                              int nb, int nbpad, int G, float eps, float *__restrict__ Cb,
-                                                              float *__restrict__ nhc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nbpad) return;
-    const bool live = i < nb && radius[i] >= 0.f;
-    float sq = 0.f;
-    for (int k = 0; k < G * 8; k += 4) {
-        const int ks = k >> 4, hb = (k >> 3) & 1, e0 = k & 4;
-        unsigned short *fh = reinterpret_cast<unsigned short *>(Cb + ((((long)i >> 5) * G + 2 * ks) * 64 + hb * 32 + (i & 31)) * 4);
-        unsigned short *fl = fh + 512;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = live ? centre[(long)i * G * 8 + k + j] : 0.f;
-            sq = fmaf(v, v, sq);
-            const __bf16 hi = (__bf16)v;
-            const __bf16 lo = (__bf16)(v - (float)hi);
-            fh[e0 + j] = __builtin_bit_cast(unsigned short, hi);
-            fl[e0 + j] = __builtin_bit_cast(unsigned short, lo);
-        }
-    }
-    const float R = live ? radius[i] + eps + CL_SPH_MARGIN : 0.f;
-    nhc[i] = live ? 0.5f * (R * R - sq) : -__builtin_inff();
-}
-
 // One workgroup per block A (wave = 32 of its points, operands in registers as in the pair kernel), every tile of 32
 // centres in turn: D = C . X^T on the matrix pipe (hi.hi + hi.lo + lo.hi), accumulators started at (R^2 - |c|^2) / 2, so
 //   |x - c|^2 <= R^2   <=>   acc >= |x|^2 / 2;
@@ -1548,7 +1556,7 @@ struct ClWs {
     unsigned char *core;
     unsigned long long *stats;
     float *centre, *radius;
-    float *Cb, *nhc;   // centres in the fragment layout of Xb, and their accumulator start values (cl_pack_centres_kernel)
+    float *Cb, *nhc;   // centres in the fragment layout of Xb, and their accumulator start values (cl_pack_centre, from cl_sphere_kernel)
     int *act_cnt, *act_list;
     unsigned char *hit, *reach;
     unsigned *key_a, *key_b;   // working order: code of every row, double-buffered for the sort
@@ -1788,7 +1796,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     if (rc) return rc;
     const int nb128 = (int)(Npad / 128);
     hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (3 * 8 * G + 4), stream, w.Xp, w.nrm, G, w.centre,
-                       w.radius);
+                       w.radius, p2n_cluster_refines() ? w.Cb : nullptr, w.nhc, nb128, (nb128 + 31) / 32 * 32, (float)eps);
     if (!p2n_cluster_refines())
         hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
                            8 * G, (float)eps, w.act_cnt, w.act_list);
@@ -1796,8 +1804,6 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     if (p2n_cluster_refines()) {
         P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));
         const int ntile = (nb128 + 31) / 32;
-        hipLaunchKernelGGL(cl_pack_centres_kernel, dim3((ntile * 32 + 255) / 256), dim3(256), 0, stream, w.centre, w.radius, nb128, ntile * 32,
-                           G, (float)eps, w.Cb, w.nhc);
         if (G == 8)
             hipLaunchKernelGGL(cl_reach_kernel<8>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         else if (G == 16)
