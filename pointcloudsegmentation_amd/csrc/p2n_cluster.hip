@@ -1203,53 +1203,59 @@ __global__ __launch_bounds__(256) void cl_active_kernel(const float *__restrict_
 //   |x - c|^2 <= R^2   <=>   acc >= |x|^2 / 2;
 // a ballot per accumulator register tells whether any of the wave's points reaches that centre's sphere.  Dense
 // (166k points x 1,301 centres x 64 = 28 GFLOP on bf16 MFMAs) it is cheaper than the listed pairs were on the vector ALU.
-template <int G>
-__global__ __launch_bounds__(256) void cl_reach_kernel(const float *__restrict__ Xb, const float *__restrict__ nh,
-                                                       const float *__restrict__ Cb, const float *__restrict__ nhc, int nb,
-                                                       int ntile, unsigned char *__restrict__ reach) {
+template <int G, int NS>   // NS: sets of 32 points per wave (2 where the registers allow: a tile's centre fragments are then
+                           // fetched once for 64 points -- the kernel is bound by that traffic through the L1, not by the matrix pipe)
+__global__ __launch_bounds__(256 / NS) void cl_reach_kernel(const float *__restrict__ Xb, const float *__restrict__ nh,
+                                                            const float *__restrict__ Cb, const float *__restrict__ nhc, int nb,
+                                                            int ntile, unsigned char *__restrict__ reach) {
     constexpr int KS = G / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const long A = blockIdx.x, i0 = (A * 4 + wave) * 32;
-    cl_bf16x8 ah[KS], al[KS];
+    const long A = blockIdx.x;
+    cl_bf16x8 ah[NS][KS], al[NS][KS];
+    // D = X . C^T: a lane holds one centre's column, its 16 registers 16 of the set's points (register r of lane half
+    // h: point 8 (r / 4) + 4 h + r % 4).  The accumulators start at (R^2 - |c|^2) / 2 - (|x|^2 / 2 - slack), so a
+    // point reaches the centre's sphere where its register ends >= 0, and "any of the lane's points" is a maximum
+    // inside the lane: no ballot per register and no mask arithmetic on the scalar unit (the earlier form, centres as
+    // rows and a ballot per register, spent ~100 scalar instructions per tile on the 32 votes).
+    float mh[NS][16];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        ah[ks] = *reinterpret_cast<const cl_bf16x8 *>(Xb + ((i0 >> 5) * G + 2 * ks) * 256 + lane * 4);
-        al[ks] = *reinterpret_cast<const cl_bf16x8 *>(Xb + ((i0 >> 5) * G + 2 * ks + 1) * 256 + lane * 4);
+    for (int s = 0; s < NS; ++s) {
+        const long i0 = (A * 4 + wave * NS + s) * 32;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ah[s][ks] = *reinterpret_cast<const cl_bf16x8 *>(Xb + ((i0 >> 5) * G + 2 * ks) * 256 + lane * 4);
+            al[s][ks] = *reinterpret_cast<const cl_bf16x8 *>(Xb + ((i0 >> 5) * G + 2 * ks + 1) * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mh[s][r] = nh[i0 + 8 * (r >> 2) + 4 * h + (r & 3)] + CL_REACH_SLACK;   // (-inf on pad rows: reach nothing)
     }
-    const float hx = -nh[i0 + (lane & 31)] - CL_REACH_SLACK;   // |x|^2 / 2 - slack (+inf on pad rows: reaches nothing)
     // (fetching a tile's centre fragments one tile ahead was tried: 139 -> 183 us, the other waves of the SIMD hide the
     // loads better than the extra registers allow)
     for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y) {
-        f32x16 acc;
+        const float start = nhc[jt * 32 + (lane & 31)];
+        f32x16 acc[NS];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(nhc + jt * 32 + 8 * gq + 4 * h);
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * gq + q] = v[q];
-        }
+            for (int r = 0; r < 16; ++r) acc[s][r] = start + mh[s][r];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const cl_bf16x8 bh = *reinterpret_cast<const cl_bf16x8 *>(Cb + ((long)jt * G + 2 * ks) * 256 + lane * 4);
             const cl_bf16x8 bl = *reinterpret_cast<const cl_bf16x8 *>(Cb + ((long)jt * G + 2 * ks + 1) * 256 + lane * 4);
-            acc = MFMAB(bh, ah[ks], acc);
-            acc = MFMAB(bh, al[ks], acc);
-            acc = MFMAB(bl, ah[ks], acc);
-        }
-        // register r of lane half h belongs to centre 8 (r / 4) + 4 h + r % 4 of the tile: the 32 votes are collected in
-        // two scalar masks (bit r: some lane of that half reaches), then lane L < 32 writes centre L's byte -- one store
-        // per tile instead of thirty-two branches
-        unsigned m0 = 0u, m1 = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(acc[r] >= hx);
-            m0 |= ((unsigned)m != 0u ? 1u : 0u) << r;
-            m1 |= ((unsigned)(m >> 32) != 0u ? 1u : 0u) << r;
+            for (int s = 0; s < NS; ++s) {
+                acc[s] = MFMAB(ah[s][ks], bh, acc[s]);
+                acc[s] = MFMAB(al[s][ks], bh, acc[s]);
+                acc[s] = MFMAB(ah[s][ks], bl, acc[s]);
+            }
         }
-        {
-            const int L = lane & 31, r = 4 * (L >> 3) + (L & 3), col = jt * 32 + L;
-            const unsigned mm = (L >> 2) & 1 ? m1 : m0;
-            if (lane < 32 && (mm >> r & 1u) && col < nb) reach[A * nb + col] = 1;   // four waves may write the same 1
-        }
+        float best = -__builtin_inff();
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) best = fmaxf(best, fmaxf(acc[s][r], acc[s][r + 1]));
+        const int col = jt * 32 + (lane & 31);
+        if (best >= 0.f && col < nb) reach[A * nb + col] = 1;   // both lane halves and the block's waves may write the same 1
     }
 }
 
@@ -1804,12 +1810,17 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     if (p2n_cluster_refines()) {
         P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));
         const int ntile = (nb128 + 31) / 32;
+        // the tiles of a block shared out over gy workgroups: the kernel waits on its centre fragments, and wants all the
+        // waves a SIMD holds (8 x 1,024 SIMDs) -- at 166k points one workgroup per block is 5 per SIMD (107 -> 98 us with two)
+        int gy = (8192 + 4 * nb128 - 1) / (4 * nb128);
+        gy = gy > 8 ? 8 : gy;
+        gy = gy > ntile ? ntile : gy;
         if (G == 8)
-            hipLaunchKernelGGL(cl_reach_kernel<8>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
+            hipLaunchKernelGGL((cl_reach_kernel<8, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         else if (G == 16)
-            hipLaunchKernelGGL(cl_reach_kernel<16>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
+            hipLaunchKernelGGL((cl_reach_kernel<16, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         else
-            hipLaunchKernelGGL(cl_reach_kernel<32>, dim3(nb128), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
+            hipLaunchKernelGGL((cl_reach_kernel<32, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         hipLaunchKernelGGL(cl_relist_kernel, dim3(nb128 / 2), dim3(256), 0, stream, (const unsigned char *)nullptr, (const int *)nullptr,
                            w.reach, nb128, sym, w.act_cnt, w.act_list);
     }
