@@ -171,12 +171,21 @@ __device__ __forceinline__ void cl_stage_rows(float *tile, int S, const float *_
     __syncthreads();
 }
 
+// what the block-sphere stage leaves (cl_sphere_kernel, or the staged cl_normalize_kernel on its way out)
+struct ClSphereOut {
+    float *centre, *radius;   // [nb][8G], [nb]
+    float *Cb, *nhc;          // the reach stage's packed centres (nullptr: no reach stage)
+    int nb, nbpad;
+    float eps;
+};
+__device__ void cl_block_sphere_from_tile(const float *tile, int S, int D, int G, int nreal, int b, const ClSphereOut &sp);
+
 // thread per point.  out_rm (N,D) row-major and/or the fragment image Xp + fp32 squared norms.
 template <bool STAGED>
 __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restrict__ emb, long N, long Npad, int D, int G,
                                                            float *__restrict__ out_rm, float *__restrict__ Xp,
                                                            float *__restrict__ nrm, float *__restrict__ Xb,
-                                                           const int *__restrict__ perm) {
+                                                           const int *__restrict__ perm, ClSphereOut sp) {
     extern __shared__ float tile[];   // STAGED: [blockDim.x][D | 1]
     const long i0 = (long)blockIdx.x * blockDim.x;
     const long i = i0 + threadIdx.x;
@@ -212,9 +221,10 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
                 }
                 v[j] = (k + j < D) ? (float)((double)x / (double)den) : 0.f;
                 sq += (double)v[j] * (double)v[j];
-                if (out_rm && k + j < D) {
-                    if constexpr (STAGED) mine[k + j] = v[j];   // (copied out by whole lines below)
-                    else out_rm[i * D + k + j] = v[j];
+                if constexpr (STAGED) {
+                    if ((out_rm || sp.centre) && k + j < D) mine[k + j] = v[j];   // (copied out by whole lines / summed per block below)
+                } else {
+                    if (out_rm && k + j < D) out_rm[i * D + k + j] = v[j];
                 }
             }
             if (Xp) {
@@ -247,6 +257,11 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
             for (int r = wave; r < nrows; r += nw)
                 for (int c = lane; c < D; c += 64) out_rm[(i0 + r) * D + c] = tile[r * S + c];
+        }
+        if (sp.centre) {   // the workgroup's CL_STAGE_ROWS = 128 rows are block blockIdx.x: its bounding sphere from the rows in LDS
+            __syncthreads();
+            const long left = N - i0;
+            cl_block_sphere_from_tile(tile, S, D, G, left < 128 ? (int)(left < 0 ? 0 : left) : 128, (int)blockIdx.x, sp);
         }
     }
 }
@@ -1098,6 +1113,44 @@ __device__ __forceinline__ void cl_pack_centre(float *__restrict__ Cb, float *__
     }
 }
 
+// The same sphere as cl_sphere_kernel's, from the block's normalised rows while the staged cl_normalize_kernel still
+// has them in LDS (row r at tile + r * S, the real rows are the first nreal): the separate kernel read the 43 MB of
+// Xp again (32 us at 166k x 64).  Called by the whole workgroup of 128 threads.
+__device__ void cl_block_sphere_from_tile(const float *tile, int S, int D, int G, int nreal, int b, const ClSphereOut &sp) {
+    __shared__ float cen[CL_STAGE_DMAX];
+    __shared__ float red[2];
+    const int t = threadIdx.x, Dp = 8 * G, lane = t & 63, wave = t >> 6;
+    if (sp.Cb && b == sp.nb - 1)
+        for (int i2 = sp.nb; i2 < sp.nbpad; ++i2) cl_pack_centre(sp.Cb, sp.nhc, G, i2, nullptr, 0.f, sp.eps, t, 128);
+    if (nreal == 0) {
+        if (t == 0) sp.radius[b] = -1.f;
+        for (int k = t; k < Dp; k += 128) sp.centre[(long)b * Dp + k] = 0.f;
+        if (sp.Cb) cl_pack_centre(sp.Cb, sp.nhc, G, b, nullptr, 0.f, sp.eps, t, 128);
+        return;
+    }
+    if (t < Dp) {   // (Dp <= 128: a thread per column, conflict-free across the columns)
+        float sum = 0.f;
+        if (t < D)
+            for (int r = 0; r < nreal; ++r) sum += tile[r * S + t];
+        cen[t] = sum / (float)nreal;
+    }
+    __syncthreads();
+    float d2 = 0.f;
+    if (t < nreal)
+        for (int k = 0; k < D; ++k) {
+            const float d = tile[t * S + k] - cen[k];
+            d2 = fmaf(d, d, d2);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o));
+    if (lane == 0) red[wave] = d2;
+    __syncthreads();
+    const float rad = sqrtf(fmaxf(red[0], red[1])) + CL_SPH_MARGIN;
+    if (t == 0) sp.radius[b] = rad;
+    for (int k = t; k < Dp; k += 128) sp.centre[(long)b * Dp + k] = cen[k];
+    if (sp.Cb) cl_pack_centre(sp.Cb, sp.nhc, G, b, cen, rad, sp.eps, t, 128);
+}
+
 // (Cb != nullptr: the block's centre also goes into the reach stage's packed set, and the last block pads the set to
 // whole tiles of 32 -- a kernel of its own took 17 us for this)
 __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict__ Xp, const float *__restrict__ nh, int G,
@@ -1680,16 +1733,16 @@ static size_t cl_stage_lds_bytes(int D) { return sizeof(float) * CL_STAGE_ROWS *
 
 // rows staged through LDS up to CL_STAGE_DMAX dimensions, read in place above that
 static int cl_launch_normalize(const float *emb, long N, long Npad, int D, int G, float *out_rm, float *Xp, float *nrm, float *Xb,
-                               const int *perm, hipStream_t stream) {
+                               const int *perm, const ClSphereOut &sp, hipStream_t stream) {
     if (D <= CL_STAGE_DMAX) {
         const size_t ldsb = cl_stage_lds_bytes(D);
         P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_normalize_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         hipLaunchKernelGGL(cl_normalize_kernel<true>, dim3((unsigned)((Npad + CL_STAGE_ROWS - 1) / CL_STAGE_ROWS)), dim3(CL_STAGE_ROWS), ldsb,
-                           stream, emb, N, Npad, D, G, out_rm, Xp, nrm, Xb, perm);
+                           stream, emb, N, Npad, D, G, out_rm, Xp, nrm, Xb, perm, sp);
     } else {
         hipLaunchKernelGGL(cl_normalize_kernel<false>, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, stream, emb, N, Npad, D, G,
-                           out_rm, Xp, nrm, Xb, perm);
+                           out_rm, Xp, nrm, Xb, perm, ClSphereOut{});
     }
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
@@ -1700,7 +1753,7 @@ extern "C" int p2n_normalize_rows(const float *emb, long N, int D, float *out, v
     if (N == 0) return P2N_OK;
     P2N_REQUIRE(emb && out, "p2n_normalize_rows: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    int rc = cl_launch_normalize(emb, N, N, D, (D + 7) / 8, out, nullptr, nullptr, nullptr, nullptr, stream);
+    int rc = cl_launch_normalize(emb, N, N, D, (D + 7) / 8, out, nullptr, nullptr, nullptr, nullptr, ClSphereOut{}, stream);
     if (rc) return rc;
     return P2N_OK;
 }
@@ -1798,11 +1851,14 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         P2N_CHECK_HIP(hipMemsetAsync(w.stats + 7, 1, 1, stream));   // stats[7] = 1: this workspace holds a working order
         perm = w.perm;
     }
-    rc = cl_launch_normalize(emb, N, Npad, D, G, nullptr, w.Xp, w.nrm, w.Xb, perm, stream);
-    if (rc) return rc;
     const int nb128 = (int)(Npad / 128);
-    hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (3 * 8 * G + 4), stream, w.Xp, w.nrm, G, w.centre,
-                       w.radius, p2n_cluster_refines() ? w.Cb : nullptr, w.nhc, nb128, (nb128 + 31) / 32 * 32, (float)eps);
+    const bool staged = D <= CL_STAGE_DMAX;   // the staged normalise kernel leaves the block spheres as well
+    ClSphereOut sp{w.centre, w.radius, p2n_cluster_refines() ? w.Cb : nullptr, w.nhc, nb128, (nb128 + 31) / 32 * 32, (float)eps};
+    rc = cl_launch_normalize(emb, N, Npad, D, G, nullptr, w.Xp, w.nrm, w.Xb, perm, staged ? sp : ClSphereOut{}, stream);
+    if (rc) return rc;
+    if (!staged)
+        hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (3 * 8 * G + 4), stream, w.Xp, w.nrm, G, w.centre,
+                           w.radius, sp.Cb, w.nhc, nb128, sp.nbpad, (float)eps);
     if (!p2n_cluster_refines())
         hipLaunchKernelGGL(cl_active_kernel, dim3(nb128 / 2), dim3(256), sizeof(float) * (16 * G + 256), stream, w.centre, w.radius, nb128,
                            8 * G, (float)eps, w.act_cnt, w.act_list);
