@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256) void cl_near_kernel(const float *__restrict__ 
 // Step 3: bit = projection above its mean, at position 31 - (rank of the projection by mass near its mean, ascending).
 __global__ __launch_bounds__(256) void cl_code_kernel(const float *__restrict__ proj, const float *__restrict__ psum,
                                                       const int *__restrict__ near, long N, unsigned *__restrict__ keys,
-                                                      int *__restrict__ vals) {
+                                                      int *__restrict__ vals, unsigned long long *__restrict__ sorted_flag) {
     __shared__ int pos[32], mass[32];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sorted_flag = 1ull;   // stats[7]: this workspace holds a working order
     __shared__ float mean[32];
     if (threadIdx.x < 32) {
         int m = 0;
@@ -1576,11 +1577,14 @@ __global__ __launch_bounds__(256) void cl_label_kernel(const int *__restrict__ p
 }
 
 // working order only: the lowest caller index among the core points of every set, then the set's root filed under it
-__global__ __launch_bounds__(256) void cl_minorig_kernel(const int *__restrict__ parent, const unsigned char *__restrict__ core,
+// (it flattens on its way: every core point finds its root and names it -- parents only ever move towards the root,
+// so a reader that meets a half-flattened path still ends at the root)
+__global__ __launch_bounds__(256) void cl_minorig_kernel(int *__restrict__ parent, const unsigned char *__restrict__ core,
                                                          const int *__restrict__ perm, long N, int *__restrict__ minorig) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const bool in = i < N && core[i];
-    const int r = in ? parent[i] : -1;
+    const int r = in ? cl_find(parent, (int)i) : -1;
+    if (in && r != (int)i) CL_ST(parent + i, r);
     int v = in ? perm[i] : 0x7fffffff;
     // neighbours in the working order mostly share a root: the wave's lanes that name the first lane's root send one
     // atomic between them, the others their own
@@ -1622,6 +1626,9 @@ struct ClWs {
     int *perm, *val_b;         // working row -> caller's index (the sort's values)
     int *minorig, *owner, *chunk_cnt;
     int *blk_uni, *rb_uni;
+    float *psum;               // CL_SUM_COPIES x (32 projection sums, 32 near-mean counts)
+    char *zero_begin, *ones_begin;   // two stretches cleared by one memset each at the start of a call (cl_carve)
+    size_t zero_bytes, ones_bytes;
     void *sort_tmp;
     size_t sort_tmp_bytes;
     int *defer_q, *defer_cnt;
@@ -1666,43 +1673,50 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
     w.Xb = (float *)take(sizeof(float) * (size_t)Npad * G * 8);   // hi + lo bf16 per value: the same size
     w.nrm = (float *)take(sizeof(float) * (Npad + 64));        // + 64: the 64-dword block prefetch may overrun
     w.nrm_core = (float *)take(sizeof(float) * (Npad + 64));
-    w.cnt = (int *)take(sizeof(int) * Npad);
     w.parent = (int *)take(sizeof(int) * (Npad + 64));
     w.nbr_cnt = (int *)take(sizeof(int) * Npad);
     w.rank = (int *)take(sizeof(int) * Npad);
-    w.blk_has_core = (int *)take(sizeof(int) * (Npad / 128 + 1));
     w.core = (unsigned char *)take((size_t)Npad);
+    const size_t nb = (size_t)Npad / 128;
+    cl_chunks(Npad, w.kslots, w.kbound);
+    w.defer_waves = (long)w.kbound * CL_NW;
+    // everything that must start a call at zero sits in one stretch, everything that starts at -1 in another: a
+    // memset each at the start of the call instead of a dozen between the kernels (each one a launch on the stream)
+    const size_t z0 = o;
     w.stats = (unsigned long long *)take(sizeof(unsigned long long) * 8);
-    {
-        const size_t nb = (size_t)Npad / 128;
-        w.centre = (float *)take(sizeof(float) * nb * G * 8);
-        w.radius = (float *)take(sizeof(float) * nb);
-        w.Cb = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32) * G * 8);
-        w.nhc = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32 + 64));
-        w.act_cnt = (int *)take(sizeof(int) * nb);
-        w.act_list = (int *)take(sizeof(int) * (nb / 2 + 1) * nb);   // one row per workgroup of 256 points
-        w.hit = (unsigned char *)take((nb / 2 + 1) * nb);
-        w.reach = (unsigned char *)take(nb * nb);   // [block A][block B]: some point of A reaches B's sphere
-    }
+    w.psum = (float *)take(sizeof(float) * 64 * CL_SUM_COPIES);
+    w.cnt = (int *)take(sizeof(int) * Npad);
+    w.blk_has_core = (int *)take(sizeof(int) * (Npad / 128 + 1));
+    w.hit = (unsigned char *)take((nb / 2 + 1) * nb);
+    w.reach = (unsigned char *)take(nb * nb);   // [block A][block B]: some point of A reaches B's sphere
+    w.defer_cnt = (int *)take(sizeof(int) * (size_t)w.defer_waves * 64);   // (workgroups without work write nothing)
+    w.zero_begin = base ? base + z0 : nullptr;
+    w.zero_bytes = o - z0;
+    const size_t f0 = o;
+    w.blk_uni = (int *)take(sizeof(int) * (Npad / 128 + 2));
+    w.rb_uni = (int *)take(sizeof(int) * (Npad / 256 + 2));
+    w.owner = (int *)take(sizeof(int) * Npad);
+    w.ones_begin = base ? base + f0 : nullptr;
+    w.ones_bytes = o - f0;
+    w.centre = (float *)take(sizeof(float) * nb * G * 8);
+    w.radius = (float *)take(sizeof(float) * nb);
+    w.Cb = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32) * G * 8);
+    w.nhc = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32 + 64));
+    w.act_cnt = (int *)take(sizeof(int) * nb);
+    w.act_list = (int *)take(sizeof(int) * (nb / 2 + 1) * nb);   // one row per workgroup of 256 points
     w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
     w.key_a = (unsigned *)take(sizeof(int) * Npad);
     w.key_b = (unsigned *)take(sizeof(int) * Npad);
     w.perm = (int *)take(sizeof(int) * Npad);
     w.val_b = (int *)take(sizeof(int) * Npad);
     w.minorig = (int *)take(sizeof(int) * Npad);
-    w.owner = (int *)take(sizeof(int) * Npad);
-    w.blk_uni = (int *)take(sizeof(int) * (Npad / 128 + 2));
-    w.rb_uni = (int *)take(sizeof(int) * (Npad / 256 + 2));
     w.chunk_cnt = (int *)take(sizeof(int) * (Npad / (1024 * CL_RANK_PT) + 2));
     w.sort_tmp_bytes = (size_t)Npad * 8 + (4u << 20);   // the double-buffered radix sort needs its digit counts only; checked at the call
     w.sort_tmp = take(w.sort_tmp_bytes);
-    cl_chunks(Npad, w.kslots, w.kbound);
     w.work_rb = (int *)take(sizeof(int) * w.kbound);
     w.work_e0 = (int *)take(sizeof(int) * w.kbound);
     w.work_meta = (int *)take(sizeof(int) * 4);
-    w.defer_waves = (long)w.kbound * CL_NW;
     w.defer_q = (int *)take(sizeof(int) * (size_t)w.defer_waves * CL_DEFER_CAP * 64);
-    w.defer_cnt = (int *)take(sizeof(int) * (size_t)w.defer_waves * 64);
     return o;
 }
 
@@ -1821,14 +1835,15 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     }
     const unsigned nb256 = (unsigned)((Npad + 255) / 256);
     int ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
-    P2N_CHECK_HIP(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * 8, stream));
+    P2N_CHECK_HIP(hipMemsetAsync(w.zero_begin, 0, w.zero_bytes, stream));      // stats, sums, counts, flags, queue lengths (cl_carve)
+    P2N_CHECK_HIP(hipMemsetAsync(w.ones_begin, 0xff, w.ones_bytes, stream));   // the link pass's notes, owner: -1
+    if (p2n_cluster_sorts(N)) P2N_CHECK_HIP(hipMemsetAsync(w.minorig, 0x7f, sizeof(int) * N, stream));   // (cl_minorig_kernel takes minima)
     const int *perm = nullptr;
     if (p2n_cluster_sorts(N)) {   // the working order (cl_code_kernel)
         // (the projections borrow Xp, which cl_normalize_kernel fills afterwards: 32 of its >= 64 floats per row; their
-        // sums and near-threshold counts (CL_SUM_COPIES copies of each) the first 1,024 words of the sort's scratch, which the sort does not touch before cl_code_kernel has run)
-        float *psum = reinterpret_cast<float *>(w.sort_tmp);
+        // sums and near-threshold counts, CL_SUM_COPIES copies of each, start at zero with the rest of the cleared stretch)
+        float *psum = w.psum;
         int *near = reinterpret_cast<int *>(psum + 32 * CL_SUM_COPIES);
-        P2N_CHECK_HIP(hipMemsetAsync(psum, 0, 64 * CL_SUM_COPIES * sizeof(float), stream));
         if (D >= 32 && D <= CL_STAGE_DMAX) {   // (the staged kernel hands its 32 results out through the row's own LDS)
             const size_t ldsb = cl_stage_lds_bytes(D);
             P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_project_kernel<true>),
@@ -1839,7 +1854,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
             hipLaunchKernelGGL(cl_project_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, emb, N, D, w.Xp, psum);
         }
         hipLaunchKernelGGL(cl_near_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, N, (float)eps, near);
-        hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, near, N, w.key_a, w.perm);
+        hipLaunchKernelGGL(cl_code_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w.Xp, psum, near, N, w.key_a, w.perm, w.stats + 7);
         rocprim::double_buffer<unsigned> kb(w.key_a, w.key_b);
         rocprim::double_buffer<int> vb(w.perm, w.val_b);
         size_t tmp = 0;
@@ -1848,7 +1863,6 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         P2N_CHECK_HIP(rocprim::radix_sort_pairs(w.sort_tmp, tmp, kb, vb, (size_t)N, 0, 32, stream));
         if (vb.current() != w.perm)
             P2N_CHECK_HIP(hipMemcpyAsync(w.perm, vb.current(), sizeof(int) * N, hipMemcpyDeviceToDevice, stream));
-        P2N_CHECK_HIP(hipMemsetAsync(w.stats + 7, 1, 1, stream));   // stats[7] = 1: this workspace holds a working order
         perm = w.perm;
     }
     const int nb128 = (int)(Npad / 128);
@@ -1864,7 +1878,6 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
                            8 * G, (float)eps, w.act_cnt, w.act_list);
     const int sym = p2n_cluster_refines() && p2n_cluster_symmetric();   // (the halved lists are made by the reach stage's relist)
     if (p2n_cluster_refines()) {
-        P2N_CHECK_HIP(hipMemsetAsync(w.reach, 0, (size_t)nb128 * nb128, stream));
         const int ntile = (nb128 + 31) / 32;
         // the tiles of a block shared out over gy workgroups: the kernel waits on its centre fragments, and wants all the
         // waves a SIMD holds (8 x 1,024 SIMDs) -- at 166k points one workgroup per block is 5 per SIMD (107 -> 98 us with two)
@@ -1880,10 +1893,6 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         hipLaunchKernelGGL(cl_relist_kernel, dim3(nb128 / 2), dim3(256), 0, stream, (const unsigned char *)nullptr, (const int *)nullptr,
                            w.reach, nb128, sym, w.act_cnt, w.act_list);
     }
-    P2N_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * Npad, stream));
-    P2N_CHECK_HIP(hipMemsetAsync(w.defer_cnt, 0, sizeof(int) * (size_t)w.defer_waves * 64, stream));   // workgroups without work write nothing
-    P2N_CHECK_HIP(hipMemsetAsync(w.blk_has_core, 0, sizeof(int) * (Npad / 128 + 1), stream));
-    P2N_CHECK_HIP(hipMemsetAsync(w.hit, 0, (size_t)(nb128 / 2) * nb128, stream));
     p2n_prof_end(ps, stream);
 
     ClArgs a;
@@ -1924,9 +1933,7 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     a.nsplit = cl_nsplit(Npad);
     a.blk_uni = nullptr; a.rb_uni = nullptr;
     if (p2n_cluster_link_notes()) {
-        P2N_CHECK_HIP(hipMemsetAsync(w.blk_uni, 0xff, sizeof(int) * (Npad / 128 + 2), stream));
-        P2N_CHECK_HIP(hipMemsetAsync(w.rb_uni, 0xff, sizeof(int) * (Npad / 256 + 2), stream));
-        a.blk_uni = w.blk_uni; a.rb_uni = w.rb_uni;
+        a.blk_uni = w.blk_uni; a.rb_uni = w.rb_uni;   // (-1 since the start of the call)
     }
     if (G == 8) rc = cl_launch_pairs<8, 4>(1, a, (int)nrowblk, stream);
     else if (G == 16) rc = cl_launch_pairs<16, 2>(1, a, (int)nrowblk, stream);
@@ -1937,9 +1944,6 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     ps = p2n_prof_begin(P2N_K_CLUSTER_PREP, stream);
     if (perm) {   // number the sets by the caller's indices
         const unsigned nbn = (unsigned)((N + 255) / 256);
-        hipLaunchKernelGGL(cl_flatten_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, N);
-        P2N_CHECK_HIP(hipMemsetAsync(w.minorig, 0x7f, sizeof(int) * N, stream));
-        P2N_CHECK_HIP(hipMemsetAsync(w.owner, 0xff, sizeof(int) * N, stream));
         hipLaunchKernelGGL(cl_minorig_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, perm, N, w.minorig);
         hipLaunchKernelGGL(cl_owner_kernel, dim3(nbn), dim3(256), 0, stream, w.parent, w.core, N, w.minorig, w.owner);
     }
