@@ -94,6 +94,9 @@ __device__ __forceinline__ float cl_np_sumsq(const float *e, int n) {
 // copies its rows into LDS, a wave per row (whole lines, each fetched once), row r at tile + r * S with S odd: a
 // thread reading its own row from there meets no bank conflict.  The arithmetic is the same, value for value.
 #define CL_STAGE_DMAX 128
+#ifndef CL_UNIT_VOTE
+#define CL_UNIT_VOTE 1   // the pair passes vote per finished unit whether it holds any candidate at all (cl_pair_kernel)
+#endif
 #define CL_SUM_COPIES 16   // copies of the projections' sums and near-mean counts (cl_project_kernel)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CL_STAGE_ROWS 128   // threads (= rows) per workgroup of the staged kernels: 128 * 129 floats = 64.5 KiB at most
@@ -956,7 +959,17 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         const long col0 = jb_cur * JB + u * UT * 32;
         const int before = cntm;
         int colv = 0;
-        if (active && prev_active) {   // the steady state: one straight-line block, compares between the MFMAs
+        // Most finished units hold no candidate pair at all (the lists are 2.4 x the cells that interact, and inside
+        // those most 32 x 64 units are empty too): the largest of a lane's values against the lane's "maybe"
+        // threshold, one vote, and the per-value compares, counts and column votes are left out.
+        bool pairs = prev_active;
+        if (CL_UNIT_VOTE && prev_active) {
+            float mx = accp[0][0];
+#pragma unroll
+            for (int e = 1; e < EL; ++e) mx = fmaxf(mx, accp[e >> 4][e & 15]);
+            pairs = __builtin_amdgcn_ballot_w64(mx >= hm) != 0ull;
+        }
+        if (active && pairs) {   // the steady state: one straight-line block, compares between the MFMAs
             init_acc(accn, blk, u);
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) {
@@ -970,7 +983,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) mfma_slot(accn, ubuf, sl);
             }
-            if (prev_active) {
+            if (pairs) {
 #pragma unroll
                 for (int e = 0; e < EL; ++e) fast_pair(accp, e, colv);
             }
@@ -981,7 +994,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             const int cp = common_parent(pnext);
             if (lane == 0) lds[CL_PU_BASE + (int)((t + 1) % 3) * 2 + wave - 2] = __int_as_float(cp);
         }
-        if (SYM && prev_active && (col0_prev >> 7) > 2L * rb + 1 && lane < UT * 32)   // (the row block's own two blocks are visited both ways round)
+        if (SYM && pairs && (col0_prev >> 7) > 2L * rb + 1 && lane < UT * 32)   // (the row block's own two blocks are visited both ways round)
             atomicAdd(reinterpret_cast<int *>(const_cast<float *>(par_prev)) + u_prev * UT * 32 + lane, colv);
         if (prev_active) {
             // Pass 1 notes which streamed blocks held any candidate pair at all for this row block: pass 2 tests the
