@@ -962,12 +962,24 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
         // Most finished units hold no candidate pair at all (the lists are 2.4 x the cells that interact, and inside
         // those most 32 x 64 units are empty too): the largest of a lane's values against the lane's "maybe"
         // threshold, one vote, and the per-value compares, counts and column votes are left out.
-        bool pairs = prev_active;
+        bool pairs = prev_active, full = false;
         if (CL_UNIT_VOTE && prev_active) {
             float mx = accp[0][0];
 #pragma unroll
             for (int e = 1; e < EL; ++e) mx = fmaxf(mx, accp[e >> 4][e & 15]);
             pairs = __builtin_amdgcn_ballot_w64(mx >= hm) != 0ull;
+            if (P1 && pairs) {   // and the other end: every value of every lane definitely inside (a unit in the middle of an instance)
+                float mn = accp[0][0];
+#pragma unroll
+                for (int e = 1; e < EL; ++e) mn = fminf(mn, accp[e >> 4][e & 15]);
+                if (__builtin_amdgcn_ballot_w64(mn >= hd) == ~0ull) {
+                    cntd += EL;
+                    cntm += EL;
+                    colv = 32;   // each of the unit's 64 streamed points has all 32 points of this wave inside
+                    pairs = false;
+                    full = true;
+                }
+            }
         }
         if (active && pairs) {   // the steady state: one straight-line block, compares between the MFMAs
             init_acc(accn, blk, u);
@@ -994,7 +1006,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
             const int cp = common_parent(pnext);
             if (lane == 0) lds[CL_PU_BASE + (int)((t + 1) % 3) * 2 + wave - 2] = __int_as_float(cp);
         }
-        if (SYM && pairs && (col0_prev >> 7) > 2L * rb + 1 && lane < UT * 32)   // (the row block's own two blocks are visited both ways round)
+        if (SYM && (pairs || full) && (col0_prev >> 7) > 2L * rb + 1 && lane < UT * 32)   // (the row block's own two blocks are visited both ways round)
             atomicAdd(reinterpret_cast<int *>(const_cast<float *>(par_prev)) + u_prev * UT * 32 + lane, colv);
         if (prev_active) {
             // Pass 1 notes which streamed blocks held any candidate pair at all for this row block: pass 2 tests the
