@@ -102,7 +102,10 @@ def predict_many(model, scenes, eps: float = 0.1, min_samples: int = 50, overlap
         labels_h, emb_h, cs_h, num_h, _ = ring[slot]
         ev.synchronize()
         cs = cs_h.numpy()
-        return {"instance_labels": labels_h[:n].numpy().copy(), "embeddings": emb_h[:n].numpy().copy(),
+        # (copied out by torch: its large copies run on all the host threads, numpy's on one -- at 150,000 points that
+        # one-thread copy of 38 MB of embeddings, not the GPU, set the time per scene once the clustering had become fast)
+        emb_o = torch.empty((n, emb_h.shape[1]), dtype=emb_h.dtype).copy_(emb_h[:n])
+        return {"instance_labels": labels_h[:n].numpy().copy(), "embeddings": emb_o.numpy(),
                 "num_instances": int(num_h[0]) - 1, "centroid": cs[:3].copy(), "scale": np.float64(cs[3])}
 
     pending = None
