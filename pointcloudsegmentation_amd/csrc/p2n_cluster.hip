@@ -17,15 +17,19 @@
 //
 // Which pairs: 256-row workgroups against blocks of 128 rows, and only the block pairs that can hold
 // a pair within eps.  The stages before pass 1 see to that:
-//   working order   rows sorted by a 32-bit code of their embedding (cl_project/code_kernel, rocPRIM
+//   working order   rows sorted by a 32-bit code of their embedding (cl_project/near/code_kernel, rocPRIM
 //                   sort), so that a block's rows are neighbours in the embedding whatever order
 //                   the caller's scan came in; labels / counts / cluster numbers go back in the
 //                   caller's indices (cl_minorig/owner/rank/label_kernel);
-//   spheres         bounding sphere per block, list of the blocks whose spheres reach (cl_sphere/active);
+//   spheres         bounding sphere per block -- taken by cl_normalize_kernel from the rows it has staged in
+//                   LDS (D <= 128; cl_sphere_kernel beyond), which also packs the centres for the next stage;
+//                   the list of blocks whose spheres reach (cl_active_kernel) only with P2N_CL_REACH=0;
 //   reach           any point of A within eps of B's sphere AND the other way round (cl_reach_kernel,
 //                   dense on the matrix pipe; cl_relist_kernel);
 //   plan            pass 1's lists cut into chunks of equal length, one workgroup each (cl_plan_kernel);
 //   hits            pass 1 notes per (row block, block) whether any candidate pair showed up: pass 2's lists.
+// Inside the passes a finished 32 x 64 unit is first put to a vote (any value near the threshold at all? every
+// value inside?) before its values are looked at one by one (unit_step in cl_pair_kernel).
 //
 // Layout: the normalised rows are stored once as MFMA fragments
 //   Xp[tile = point/32][g = k/8][lane = 32*h + point%32][j]  = x[point][8g + 4h + j]
