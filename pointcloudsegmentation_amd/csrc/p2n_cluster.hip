@@ -296,7 +296,30 @@ constexpr ClSigns cl_make_signs() {
 }
 __constant__ ClSigns cl_signs = cl_make_signs();
 
-template <bool STAGED>
+constexpr bool cl_sign_neg(int d, int k) {   // the table's entry as a compile-time fact
+    unsigned hsh = (unsigned)d * 0x9E3779B1u + 0x7F4A7C15u;
+    hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
+    return (hsh >> k & 1u) != 0u;
+}
+template <int D0, int K0>
+__device__ __forceinline__ void cl_project_dim_c(float (&acc)[32], float x) {
+    if constexpr (K0 < 32) {
+        acc[K0] = cl_sign_neg(D0, K0) ? acc[K0] - x : acc[K0] + x;
+        cl_project_dim_c<D0, K0 + 1>(acc, x);
+    }
+}
+template <int D0, int DC>
+__device__ __forceinline__ void cl_project_dims_c(float (&acc)[32], float &ss, const float *mine) {
+    if constexpr (D0 < DC) {
+        const float x = mine[D0];
+        ss = fmaf(x, x, ss);
+        cl_project_dim_c<D0, 0>(acc, x);
+        cl_project_dims_c<D0 + 1, DC>(acc, ss, mine);
+    }
+}
+
+template <bool STAGED, int DC = 0>   // DC: the row length as a compile-time constant (0: read from D): the signs are then
+                                     // part of the instruction stream (an add or a subtract), no table loads at all
 __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict__ emb, long N, int D, float *__restrict__ proj,
                                                          float *__restrict__ psum) {
     __shared__ float part[4][32];
@@ -322,7 +345,9 @@ __global__ __launch_bounds__(256) void cl_project_kernel(const float *__restrict
 #pragma unroll
             for (int k = 0; k < 32; ++k) acc[k] = fmaf(x, sg[k], acc[k]);
         };
-        if constexpr (STAGED) {
+        if constexpr (STAGED && DC > 0) {
+            cl_project_dims_c<0, DC>(acc, ss, mine);
+        } else if constexpr (STAGED) {
             int d = 0;
             for (; d + 1 < D; d += 2) {   // (two dimensions' sign loads and LDS reads in flight)
                 const float x0 = mine[d], x1 = mine[d + 1];
@@ -1877,6 +1902,12 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
             const size_t ldsb = cl_stage_lds_bytes(D);
             P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_project_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            if (D == 64) {
+                P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_project_kernel<true, 64>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+                hipLaunchKernelGGL((cl_project_kernel<true, 64>), dim3((unsigned)((N + CL_STAGE_ROWS - 1) / CL_STAGE_ROWS)), dim3(CL_STAGE_ROWS), ldsb,
+                                   stream, emb, N, D, w.Xp, psum);
+            } else
             hipLaunchKernelGGL(cl_project_kernel<true>, dim3((unsigned)((N + CL_STAGE_ROWS - 1) / CL_STAGE_ROWS)), dim3(CL_STAGE_ROWS), ldsb,
                                stream, emb, N, D, w.Xp, psum);
         } else {
