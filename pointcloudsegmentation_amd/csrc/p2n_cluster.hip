@@ -184,7 +184,6 @@ struct ClSphereOut {
     float *Cb, *nhc;          // the reach stage's packed centres (nullptr: no reach stage)
     int nb, nbpad;
     float eps;
-    float *nrmS;              // per row -|x_S|^2 / 2 over the first 16 dimensions (the reach stage's first look), or nullptr
 };
 __device__ void cl_block_sphere_from_tile(const float *tile, int S, int D, int G, int nreal, int b, const ClSphereOut &sp);
 
@@ -207,7 +206,6 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
                 *reinterpret_cast<f32x4 *>(Xb + (((i >> 5) * G + g) * 64 + h * 32 + (i & 31)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             nrm[i] = -__builtin_inff();
-            if (sp.nrmS) sp.nrmS[i] = -__builtin_inff();
         }
     }
     if (i < N) {
@@ -218,9 +216,8 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
         else ss = cl_np_sumsq<2>(eg, D);
         // sqrt and divide through double: correctly rounded in fp32 (53 >= 2*24+2) whatever the fp32 fast paths do
         const float den = __fadd_rn((float)sqrt((double)ss), 1e-8f);
-        double sq = 0.0, sqS = 0.0;
+        double sq = 0.0;
         for (int k = 0; k < G * 8; k += 8) {
-            if (k == 16) sqS = sq;   // (the first two pieces: dimensions 0..15)
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -258,7 +255,6 @@ __global__ __launch_bounds__(256) void cl_normalize_kernel(const float *__restri
             }
         }
         if (Xp) nrm[i] = (float)(-0.5 * sq);   // nh = -|x|^2/2, the accumulator start value of the pair passes
-        if (sp.nrmS) sp.nrmS[i] = (float)(-0.5 * (G * 8 > 16 ? sqS : sq));
     }
     if constexpr (STAGED) {
         if (out_rm) {   // rows i0.. are one stretch of out_rm
@@ -1149,7 +1145,7 @@ __global__ __launch_bounds__(CL_NW * 64, 2) void cl_pair_kernel(ClArgs A) {   //
 // cl_reach_kernel, and its accumulator start value (R^2 - |c|^2) / 2, R = radius + eps + margin (-inf: empty block
 // or padding, cen == nullptr).  Called by a whole workgroup: thread k writes dimension k's two halves.
 __device__ __forceinline__ void cl_pack_centre(float *__restrict__ Cb, float *__restrict__ nhc, int G, int i, const float *cen,
-                                               float rad, float eps, int t, int nthreads, int soff) {
+                                               float rad, float eps, int t, int nthreads) {
     const int Dp = 8 * G;
     for (int k = t; k < Dp; k += nthreads) {
         const float v = cen ? cen[k] : 0.f;
@@ -1161,20 +1157,14 @@ __device__ __forceinline__ void cl_pack_centre(float *__restrict__ Cb, float *__
         fh[512 + e] = __builtin_bit_cast(unsigned short, lo);   // the lo fragment follows the hi fragment
     }
     if (t == 0) {
-        float start = -__builtin_inff(), startS = -__builtin_inff();
+        float start = -__builtin_inff();
         if (cen) {
-            float sq = 0.f, sqS = 0.f;
-            for (int k = 0; k < Dp; ++k) {
-                if (k == 16) sqS = sq;
-                sq = fmaf(cen[k], cen[k], sq);
-            }
-            if (Dp <= 16) sqS = sq;
+            float sq = 0.f;
+            for (int k = 0; k < Dp; ++k) sq = fmaf(cen[k], cen[k], sq);
             const float R = rad + eps + CL_SPH_MARGIN;
             start = 0.5f * (R * R - sq);
-            startS = 0.5f * (R * R - sqS);
         }
         nhc[i] = start;
-        nhc[soff + i] = startS;   // the same over the first 16 dimensions only (the reach stage's first look)
     }
 }
 
@@ -1186,11 +1176,11 @@ __device__ void cl_block_sphere_from_tile(const float *tile, int S, int D, int G
     __shared__ float red[2];
     const int t = threadIdx.x, Dp = 8 * G, lane = t & 63, wave = t >> 6;
     if (sp.Cb && b == sp.nb - 1)
-        for (int i2 = sp.nb; i2 < sp.nbpad; ++i2) cl_pack_centre(sp.Cb, sp.nhc, G, i2, nullptr, 0.f, sp.eps, t, 128, sp.nbpad + 64);
+        for (int i2 = sp.nb; i2 < sp.nbpad; ++i2) cl_pack_centre(sp.Cb, sp.nhc, G, i2, nullptr, 0.f, sp.eps, t, 128);
     if (nreal == 0) {
         if (t == 0) sp.radius[b] = -1.f;
         for (int k = t; k < Dp; k += 128) sp.centre[(long)b * Dp + k] = 0.f;
-        if (sp.Cb) cl_pack_centre(sp.Cb, sp.nhc, G, b, nullptr, 0.f, sp.eps, t, 128, sp.nbpad + 64);
+        if (sp.Cb) cl_pack_centre(sp.Cb, sp.nhc, G, b, nullptr, 0.f, sp.eps, t, 128);
         return;
     }
     if (t < Dp) {   // (Dp <= 128: a thread per column, conflict-free across the columns)
@@ -1213,7 +1203,7 @@ __device__ void cl_block_sphere_from_tile(const float *tile, int S, int D, int G
     const float rad = sqrtf(fmaxf(red[0], red[1])) + CL_SPH_MARGIN;
     if (t == 0) sp.radius[b] = rad;
     for (int k = t; k < Dp; k += 128) sp.centre[(long)b * Dp + k] = cen[k];
-    if (sp.Cb) cl_pack_centre(sp.Cb, sp.nhc, G, b, cen, rad, sp.eps, t, 128, sp.nbpad + 64);
+    if (sp.Cb) cl_pack_centre(sp.Cb, sp.nhc, G, b, cen, rad, sp.eps, t, 128);
 }
 
 // (Cb != nullptr: the block's centre also goes into the reach stage's packed set, and the last block pads the set to
@@ -1239,11 +1229,11 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     __syncthreads();
     const float cntf = sc[0] + sc[1];
     if (Cb && b == nb - 1)
-        for (int i2 = nb; i2 < nbpad; ++i2) cl_pack_centre(Cb, nhc, G, i2, nullptr, 0.f, eps, t, 128, nbpad + 64);
+        for (int i2 = nb; i2 < nbpad; ++i2) cl_pack_centre(Cb, nhc, G, i2, nullptr, 0.f, eps, t, 128);
     if (cntf == 0.f) {
         if (t == 0) radius[b] = -1.f;
         for (int k = t; k < Dp; k += 128) centre[(long)b * Dp + k] = 0.f;
-        if (Cb) cl_pack_centre(Cb, nhc, G, b, nullptr, 0.f, eps, t, 128, nbpad + 64);
+        if (Cb) cl_pack_centre(Cb, nhc, G, b, nullptr, 0.f, eps, t, 128);
         return;
     }
     for (int k = t; k < Dp; k += 128) cen[k] = (part[k] + part[Dp + k]) / cntf;
@@ -1261,7 +1251,7 @@ __global__ __launch_bounds__(128) void cl_sphere_kernel(const float *__restrict_
     const float rad = sqrtf(fmaxf(sc[2], sc[3])) + CL_SPH_MARGIN;
     if (t == 0) radius[b] = rad;
     for (int k = t; k < Dp; k += 128) centre[(long)b * Dp + k] = cen[k];   // (up to 256 dimensions, 128 threads)
-    if (Cb) cl_pack_centre(Cb, nhc, G, b, cen, rad, eps, t, 128, nbpad + 64);
+    if (Cb) cl_pack_centre(Cb, nhc, G, b, cen, rad, eps, t, 128);
 }
 
 // grid = row groups of 256 points.  list[ib][0..cnt) = column blocks jb (ascending) that can reach either of the
@@ -1325,8 +1315,7 @@ template <int G, int NS>   // NS: sets of 32 points per wave (2 where the regist
                            // fetched once for 64 points -- the kernel is bound by that traffic through the L1, not by the matrix pipe)
 __global__ __launch_bounds__(256 / NS) void cl_reach_kernel(const float *__restrict__ Xb, const float *__restrict__ nh,
                                                             const float *__restrict__ Cb, const float *__restrict__ nhc, int nb,
-                                                            int ntile, unsigned char *__restrict__ reach,
-                                                            const float *__restrict__ nhS) {
+                                                            int ntile, unsigned char *__restrict__ reach) {
     constexpr int KS = G / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const long A = blockIdx.x;
@@ -1348,32 +1337,9 @@ __global__ __launch_bounds__(256 / NS) void cl_reach_kernel(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) mh[s][r] = nh[i0 + 8 * (r >> 2) + 4 * h + (r & 3)] + CL_REACH_SLACK;   // (-inf on pad rows: reach nothing)
     }
-    // A first look at a tile over the first 16 dimensions only (one k-step, 3 of the 12 products): the distance over
-    // a part of the dimensions is a lower bound of the distance, so a tile that no point reaches in those -- nearly
-    // every tile of another instance -- is done; the others start again with all of them.
-    static_assert(NS == 1, "the first look is written for one point set per wave");
-    const float *nhcS = nhc + ntile * 32 + 64;
-    float mhS[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mhS[r] = nhS[(A * 4 + wave) * 32 + 8 * (r >> 2) + 4 * h + (r & 3)] + CL_REACH_SLACK;
     // (fetching a tile's centre fragments one tile ahead was tried: 139 -> 183 us, the other waves of the SIMD hide the
     // loads better than the extra registers allow)
     for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y) {
-        if (KS > 1) {
-            const float startS = nhcS[jt * 32 + (lane & 31)];
-            f32x16 a0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a0[r] = startS + mhS[r];
-            const cl_bf16x8 bh = *reinterpret_cast<const cl_bf16x8 *>(Cb + ((long)jt * G) * 256 + lane * 4);
-            const cl_bf16x8 bl = *reinterpret_cast<const cl_bf16x8 *>(Cb + ((long)jt * G + 1) * 256 + lane * 4);
-            a0 = MFMAB(ah[0][0], bh, a0);
-            a0 = MFMAB(al[0][0], bh, a0);
-            a0 = MFMAB(ah[0][0], bl, a0);
-            float b0 = fmaxf(a0[0], a0[1]);
-#pragma unroll
-            for (int r = 2; r < 16; r += 2) b0 = fmaxf(b0, fmaxf(a0[r], a0[r + 1]));
-            if (!__builtin_amdgcn_ballot_w64(b0 >= 0.f)) continue;
-        }
         const float start = nhc[jt * 32 + (lane & 31)];
         f32x16 acc[NS];
 #pragma unroll
@@ -1708,7 +1674,6 @@ struct ClWs {
     unsigned long long *stats;
     float *centre, *radius;
     float *Cb, *nhc;   // centres in the fragment layout of Xb, and their accumulator start values (cl_pack_centre, from cl_sphere_kernel)
-    float *nrmS;       // -|x_S|^2 / 2 over the first 16 dimensions of every row
     int *act_cnt, *act_list;
     unsigned char *hit, *reach;
     unsigned *key_a, *key_b;   // working order: code of every row, double-buffered for the sort
@@ -1790,8 +1755,7 @@ static size_t cl_carve(ClWs &w, char *base, long Npad, int G, long N, int cap) {
     w.centre = (float *)take(sizeof(float) * nb * G * 8);
     w.radius = (float *)take(sizeof(float) * nb);
     w.Cb = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32) * G * 8);
-    w.nhc = (float *)take(sizeof(float) * 2 * ((nb + 31) / 32 * 32 + 64));   // full, then first-16-dimensions start values
-    w.nrmS = (float *)take(sizeof(float) * (Npad + 64));
+    w.nhc = (float *)take(sizeof(float) * ((nb + 31) / 32 * 32 + 64));
     w.act_cnt = (int *)take(sizeof(int) * nb);
     w.act_list = (int *)take(sizeof(int) * (nb / 2 + 1) * nb);   // one row per workgroup of 256 points
     w.nbr = (int *)take(sizeof(int) * (size_t)(N > 0 ? N : 1) * (cap > 0 ? cap : 1));
@@ -1838,8 +1802,6 @@ static size_t cl_stage_lds_bytes(int D) { return sizeof(float) * CL_STAGE_ROWS *
 // rows staged through LDS up to CL_STAGE_DMAX dimensions, read in place above that
 static int cl_launch_normalize(const float *emb, long N, long Npad, int D, int G, float *out_rm, float *Xp, float *nrm, float *Xb,
                                const int *perm, const ClSphereOut &sp, hipStream_t stream) {
-    ClSphereOut rows_only{};   // the unstaged kernel leaves the spheres to cl_sphere_kernel
-    rows_only.nrmS = sp.nrmS;
     if (D <= CL_STAGE_DMAX) {
         const size_t ldsb = cl_stage_lds_bytes(D);
         P2N_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cl_normalize_kernel<true>),
@@ -1848,7 +1810,7 @@ static int cl_launch_normalize(const float *emb, long N, long Npad, int D, int G
                            stream, emb, N, Npad, D, G, out_rm, Xp, nrm, Xb, perm, sp);
     } else {
         hipLaunchKernelGGL(cl_normalize_kernel<false>, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, stream, emb, N, Npad, D, G,
-                           out_rm, Xp, nrm, Xb, perm, rows_only);
+                           out_rm, Xp, nrm, Xb, perm, ClSphereOut{});
     }
     P2N_CHECK_HIP(hipGetLastError());
     return P2N_OK;
@@ -1965,8 +1927,8 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
     }
     const int nb128 = (int)(Npad / 128);
     const bool staged = D <= CL_STAGE_DMAX;   // the staged normalise kernel leaves the block spheres as well
-    ClSphereOut sp{w.centre, w.radius, p2n_cluster_refines() ? w.Cb : nullptr, w.nhc, nb128, (nb128 + 31) / 32 * 32, (float)eps, w.nrmS};
-    rc = cl_launch_normalize(emb, N, Npad, D, G, nullptr, w.Xp, w.nrm, w.Xb, perm, sp, stream);
+    ClSphereOut sp{w.centre, w.radius, p2n_cluster_refines() ? w.Cb : nullptr, w.nhc, nb128, (nb128 + 31) / 32 * 32, (float)eps};
+    rc = cl_launch_normalize(emb, N, Npad, D, G, nullptr, w.Xp, w.nrm, w.Xb, perm, staged ? sp : ClSphereOut{}, stream);
     if (rc) return rc;
     if (!staged)
         hipLaunchKernelGGL(cl_sphere_kernel, dim3(nb128), dim3(128), sizeof(float) * (3 * 8 * G + 4), stream, w.Xp, w.nrm, G, w.centre,
@@ -1983,11 +1945,11 @@ extern "C" int p2n_cluster_embeddings(const float *emb, long N, int D, double ep
         gy = gy > 8 ? 8 : gy;
         gy = gy > ntile ? ntile : gy;
         if (G == 8)
-            hipLaunchKernelGGL((cl_reach_kernel<8, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach, w.nrmS);
+            hipLaunchKernelGGL((cl_reach_kernel<8, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         else if (G == 16)
-            hipLaunchKernelGGL((cl_reach_kernel<16, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach, w.nrmS);
+            hipLaunchKernelGGL((cl_reach_kernel<16, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         else
-            hipLaunchKernelGGL((cl_reach_kernel<32, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach, w.nrmS);
+            hipLaunchKernelGGL((cl_reach_kernel<32, 1>), dim3(nb128, gy), dim3(256), 0, stream, w.Xb, w.nrm, w.Cb, w.nhc, nb128, ntile, w.reach);
         hipLaunchKernelGGL(cl_relist_kernel, dim3(nb128 / 2), dim3(256), 0, stream, (const unsigned char *)nullptr, (const int *)nullptr,
                            w.reach, nb128, sym, w.act_cnt, w.act_list);
     }
